@@ -1,0 +1,117 @@
+"""ctypes binding of libbigkrls_hip.so (the C ABI declared in include/bigkrls.h).
+
+There is no fallback: if the shared library is missing or a call fails, an
+exception is raised.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbigkrls_hip.so")
+
+OK, EINVAL, ENODEVICE, EHIP, ENOMEM, ENOCONV = 0, 1, 2, 3, 4, 5
+_CODES = {1: "EINVAL", 2: "ENODEVICE", 3: "EHIP", 4: "ENOMEM", 5: "ENOCONV"}
+
+
+class BigKRLSError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libbigkrls_hip: {_CODES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+i64 = C.c_int64
+f64 = C.c_double
+vp = C.c_void_p
+pf64 = C.POINTER(C.c_double)
+pi64 = C.POINTER(C.c_int64)
+pi32 = C.POINTER(C.c_int32)
+
+# name -> argtypes (every function returns int unless listed in _RESTYPES)
+SIGNATURES = {
+    "bigkrls_version": [],
+    "bigkrls_last_error": [],
+    "bigkrls_device_count": [C.POINTER(C.c_int)],
+    "bigkrls_ctx_create": [C.c_int, C.POINTER(vp)],
+    "bigkrls_ctx_create_on_stream": [C.c_int, vp, C.POINTER(vp)],
+    "bigkrls_ctx_destroy": [vp],
+    "bigkrls_ctx_sync": [vp],
+    "bigkrls_ctx_stream": [vp],
+    "bigkrls_ctx_workspace_bytes": [vp],
+    "bigkrls_ctx_release_workspace": [vp],
+    "bigkrls_dev_alloc": [vp, i64, C.POINTER(vp)],
+    "bigkrls_dev_free": [vp, vp],
+    "bigkrls_h2d": [vp, vp, vp, i64],
+    "bigkrls_d2h": [vp, vp, vp, i64],
+    "bigkrls_d2d": [vp, vp, vp, i64],
+    "bigkrls_event_create": [C.POINTER(vp)],
+    "bigkrls_event_destroy": [vp],
+    "bigkrls_event_record": [vp, vp],
+    "bigkrls_event_elapsed_ms": [vp, vp, pf64],
+    # level 1
+    "bigkrls_gauss_kernel": [vp, i64, i64, f64, vp],
+    "bigkrls_temp_kernel": [vp, i64, vp, i64, i64, f64, vp],
+    "bigkrls_eigen": [vp, i64, i64, vp, vp],
+    "bigkrls_solveforc": [vp, i64, i64, vp, i64, vp, f64, pf64, vp],
+    "bigkrls_multdiag": [vp, i64, i64, vp, vp],
+    "bigkrls_crossprod": [vp, i64, i64, vp, i64, vp],
+    "bigkrls_xtx": [vp, i64, i64, vp],
+    "bigkrls_tcrossprod": [vp, i64, i64, vp, i64, vp],
+    "bigkrls_xxt": [vp, i64, i64, vp],
+    "bigkrls_derivmat": [vp, i64, i64, vp, vp, vp, vp, vp, f64],
+    # level 2
+    "bigkrls_dev_kernel_block": [vp, vp, i64, i64, vp, i64, i64, i64, f64, vp, i64, i64],
+    "bigkrls_dev_gemm": [vp, C.c_int, C.c_int, i64, i64, i64, f64, vp, i64, vp, i64, f64, vp, i64],
+    "bigkrls_dev_multdiag": [vp, vp, i64, i64, i64, vp, vp, i64],
+    "bigkrls_dev_eigen": [vp, vp, i64, i64, i64, vp, i64, f64, vp, i64, pi64],
+    "bigkrls_dev_qty": [vp, vp, i64, i64, i64, vp, vp],
+    "bigkrls_dev_solveforc": [vp, vp, i64, i64, i64, vp, vp, f64, vp, pf64],
+    "bigkrls_dev_lambda_search": [vp, vp, i64, i64, i64, vp, vp, vp, i64, f64, f64, f64,
+                                  pf64, pi64, vp, i64],
+    "bigkrls_lambda_bounds": [vp, i64, i64, pf64, pf64],
+    "bigkrls_dev_deriv_rows": [vp, vp, i64, i64, i64, i64, vp, i64, i64, vp, vp, f64, vp, i64,
+                               vp, i64],
+    "bigkrls_dev_deriv_var": [vp, vp, i64, i64, i64, vp, vp, i64, i64, vp, vp],
+    "bigkrls_dev_gemv": [vp, C.c_int, i64, i64, f64, vp, i64, vp, f64, vp],
+    "bigkrls_dev_dot": [vp, i64, vp, vp, pf64],
+    "bigkrls_dev_diag": [vp, vp, i64, i64, vp],
+    "bigkrls_dev_scale": [vp, i64, f64, vp],
+}
+_RESTYPES = {
+    "bigkrls_last_error": C.c_char_p,
+    "bigkrls_ctx_stream": vp,
+    "bigkrls_ctx_workspace_bytes": i64,
+}
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C bigkrls_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        lib = load()
+        msg = lib.bigkrls_last_error()
+        raise BigKRLSError(status, msg.decode() if msg else "")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args))

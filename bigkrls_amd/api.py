@@ -1,0 +1,366 @@
+"""bigKRLS(), predict(), crossvalidate(): host-side mirror of the reference's R API
+(R/bigKRLS.R:97-516, 547-637, 1146-1336) over HIP device buffers.
+
+The control flow, argument names (dots become underscores), defaults, validation
+messages and output fields follow the R functions so that the parity tests read
+like the reference's own; every N x N object lives in HBM as a DeviceMatrix and
+every numeric step is a HIP kernel behind the C ABI (include/bigkrls.h).
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import ops
+from .device import Context, DeviceMatrix, is_device_matrix
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def _sd(v) -> float:
+    return float(np.std(np.asarray(v, dtype=np.float64), ddof=1))
+
+
+def _var(v) -> float:
+    return float(np.var(np.asarray(v, dtype=np.float64), ddof=1))
+
+
+def _cor(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    a0, b0 = a - a.mean(), b - b.mean()
+    return float((a0 @ b0) / math.sqrt((a0 @ a0) * (b0 @ b0)))
+
+
+class BigKRLS(dict):
+    """The list `w` returned by bigKRLS() (R/bigKRLS.R:420-469), class "bigKRLS"."""
+
+    r_class = "bigKRLS"
+
+
+class BigKRLSPredicted(dict):
+    r_class = "bigKRLS_predicted"
+
+
+def _as_host_matrix(X) -> np.ndarray:
+    if is_device_matrix(X):
+        return X.to_numpy()
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    return X
+
+
+def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None, vcov_est=True,
+            Neig=None, eigtrunc=None, lambda_=None, L=None, U=None, tol=None,
+            noisy=None, ctx: Optional[Context] = None,
+            timings: Optional[Dict[str, float]] = None,
+            trace: Optional[list] = None) -> BigKRLS:
+    """Kernel-regularised least squares fit (R/bigKRLS.R:97-516).
+
+    `which_derivatives` is 1-based like R.  `lambda_` is R's `lambda`.
+    Persistence arguments (model_subfolder_name, ...) and Ncores/acf are out of
+    scope.  `timings` (optional dict) receives per-phase
+    wall-clock seconds measured with HIP events on the context's stream.
+    """
+    ctx = ctx or default_context()
+    if X is None or y is None:
+        raise ValueError("y and X are required")
+    return_big_rectangles = is_device_matrix(X)                                  # :149
+    Xh = np.array(_as_host_matrix(X), dtype=np.float64)
+    yh = np.array(_as_host_matrix(y), dtype=np.float64).ravel()
+    n, p = Xh.shape
+    return_big_squares = return_big_rectangles or n > 2500                       # :150
+    w = BigKRLS()
+    w["has.big.matrices"] = bool(return_big_squares or return_big_rectangles)
+    noisy = (n > 2000) if noisy is None else bool(noisy)                          # :153
+    xlabs = [f"x{i + 1}" for i in range(p)]                                       # :167
+    w["X"] = Xh.copy()
+    X_init_sd = Xh.std(axis=0, ddof=1) if n > 1 else np.zeros(p)                  # :179
+    if np.isnan(Xh).any():                                                        # :183-187
+        bad = [str(j + 1) for j in range(p) if np.isnan(Xh[:, j]).any()]
+        raise ValueError("the following columns in X contain missing data, which must be removed: "
+                         + ", ".join(bad))
+    Neig = min(n, int(Neig)) if Neig is not None else n                           # :194
+    if eigtrunc is None:                                                          # :195-201
+        eigtrunc = 0.001 if n > 3000 else 0.0
+    elif not np.isscalar(eigtrunc) or eigtrunc < 0 or eigtrunc > 1:
+        raise ValueError("eigtrunc must be between 0 (no truncation) and 1 (keep largest only).")
+    if which_derivatives is not None:                                             # :206-215
+        if not derivative:
+            raise ValueError("which.derivative requires derivative = TRUE")
+        which_derivatives = [int(i) for i in which_derivatives]
+        if not all(1 <= i <= p for i in which_derivatives):
+            raise ValueError("which.derivatives must index columns of X")
+    if X_init_sd.min() == 0:                                                      # :217
+        raise ValueError("The following columns in X are constant and must be removed: "
+                         + ", ".join(str(j + 1) for j in np.nonzero(X_init_sd == 0)[0]))
+    if n != yh.shape[0]:
+        raise ValueError("nrow(X) not equal to number of elements in y.")
+    if np.isnan(yh).any():
+        raise ValueError("y contains missing data.")
+    if _sd(yh) == 0:
+        raise ValueError("y is a constant.")
+    if lambda_ is not None and not (np.isscalar(lambda_) and lambda_ > 0):        # :225
+        raise ValueError("lambda must be a positive scalar")
+    if sigma is not None and not (np.isscalar(sigma) and sigma > 0):              # :227
+        raise ValueError("sigma must be a positive scalar")
+    sigma = float(p) if sigma is None else float(sigma)                           # :230
+    if tol is not None and not (np.isscalar(tol) and tol > 0):                    # :232-236
+        raise ValueError("tol must be a positive scalar")
+    if derivative and not vcov_est:                                               # :239
+        raise ValueError("vcov.est is needed to get derivatives (derivative==TRUE requires vcov.est=TRUE).")
+    x_is_binary = ops.binary_columns(Xh)                                          # :242
+
+    y_init = yh.copy()
+    y_init_sd = _sd(y_init)                                                       # :248
+    y_init_mean = float(y_init.mean())
+    Xs = (Xh - Xh.mean(axis=0)) / Xh.std(axis=0, ddof=1)                          # :251-253
+    ys = (yh - yh.mean()) / _sd(yh)                                               # :254
+
+    T = timings if timings is not None else {}
+    ev = [ctx.event()]
+    names: List[str] = []
+
+    def mark(name):
+        names.append(name)
+        ev.append(ctx.event())
+
+    t_wall0 = time.perf_counter()
+    Xd = ctx.from_numpy(Xs)
+    yd = ctx.from_numpy(ys)
+    mark("h2d")
+
+    K = ops.bGaussKernel(Xd, sigma)                                               # Step 1 (:262)
+    mark("kernel")
+    Eigenobject = ops.bEigen(K, Neig, eigtrunc)                                   # Step 2 (:266)
+    mark("eigen")
+    w["K.eigenvalues"] = Eigenobject.values                                       # :268
+    w["lastkeeper"] = Eigenobject.lastkeeper                                      # :269
+
+    if lambda_ is None:                                                           # Step 3 (:271-278)
+        lambda_ = ops.bLambdaSearch(L=L, U=U, y=yd, Eigenobject=Eigenobject, noisy=False,
+                                    trace=trace)  # NB: `tol` is not forwarded (:274-275)
+    mark("lambda")
+    vals = Eigenobject.values
+    w["Neffective"] = n - float(np.sum(vals / (vals + lambda_)))                  # :280
+
+    out = ops.bSolveForc(y=yd, Eigenobject=Eigenobject, lambda_=lambda_)          # Step 4 (:286)
+    coeffs_d = out["coeffs"]
+    yfitted_d = ops.matvec(K, coeffs_d)                                           # :291
+    coeffs = coeffs_d.to_numpy().ravel()
+    yfitted = yfitted_d.to_numpy().ravel()
+    mark("coeffs")
+
+    vcovmatc = vcovmatyhat = None
+    wv = None
+    sigmasq = None
+    if vcov_est:
+        resid = ys - yfitted
+        sigmasq = float(resid @ resid) / n                                        # :294
+        kk = Eigenobject.lastkeeper
+        wv = sigmasq * (vals[:kk] + lambda_) ** -2.0
+        m = ops.bMultDiag(Eigenobject.vectors, sigmasq * (vals + lambda_) ** -2.0)   # :299
+        vcovmatc = ops.bTCrossProd(m, Eigenobject.vectors)                        # :301
+        mark("vcov_c")
+        # :307  crossprod(K, vcovmatc %*% K) == Q diag(wv d^2) Q' because K Q = Q D on the
+        # kept pairs (4 N^3 flops -> 2 N^2 K)
+        m2 = ops.bMultDiag(Eigenobject.vectors, wv * vals[:kk] ** 2)
+        vcovmatyhat = ops.bTCrossProd(m2, Eigenobject.vectors)
+        del m, m2
+        mark("vcov_fitted")
+
+    if derivative:                                                                # Step 5 (:321-376)
+        cols = list(range(p)) if which_derivatives is None else [i - 1 for i in which_derivatives]
+        X_estimate_h = Xs[:, cols]                                                # :326
+        X_estimate = Xd if which_derivatives is None else ctx.from_numpy(X_estimate_h)
+        deriv_out = ops.bDerivatives(X_estimate, sigma, K, coeffs_d, Eigenobject, wv, X_estimate_h)
+        derivmat = deriv_out["derivatives"].to_numpy()
+        varavgderivmat = np.asarray(deriv_out["varavgderiv"], dtype=np.float64)
+        mark("derivatives")
+        w["derivatives.std"] = derivmat.copy()
+        w["var.avgderivatives.std"] = varavgderivmat.copy()
+        yhat_ame = X_estimate_h @ derivmat.mean(axis=0)                           # :390
+        w["R2AME"] = _cor(y_init, yhat_ame) ** 2                                  # :392
+        derivmat = y_init_sd * derivmat                                           # :394
+        for i in range(derivmat.shape[1]):
+            derivmat[:, i] = derivmat[:, i] / X_init_sd[i]                        # :395-397 (quirk Q6)
+        avgderiv = derivmat.mean(axis=0)[None, :]                                 # :400
+        varavgderivmat = ((y_init_sd / X_init_sd[cols]) ** 2 * varavgderivmat)[None, :]  # :403-407
+
+    w["coeffs"] = coeffs                                                          # :420
+    w["y"] = y_init
+    w["sigma"] = sigma
+    w["lambda"] = float(lambda_)
+    w["binaryindicator"] = x_is_binary
+    w["which.derivatives"] = which_derivatives
+    w["xlabs"] = xlabs
+    w["yfitted.std"] = yfitted.copy()
+    yf = yfitted * y_init_sd + y_init_mean                                        # :428
+    w["yfitted"] = yf
+    w["R2"] = 1 - (_var(y_init - yf) / (y_init_sd ** 2))                          # :429
+    w["Looe"] = out["Le"] * y_init_sd                                             # :430
+    w["Le"] = out["Le"]
+    w["sigmasq"] = sigmasq
+    w["K"] = K if return_big_squares else K.to_numpy()                            # :434
+    if vcov_est:
+        vcovmatc.scale_(y_init_sd ** 2)                                           # :438
+        vcovmatyhat.scale_(y_init_sd ** 2)                                        # :445
+        if return_big_squares:
+            w["vcov.est.c"] = vcovmatc
+            w["vcov.est.fitted"] = vcovmatyhat
+        else:
+            w["vcov.est.c"] = vcovmatc.to_numpy()
+            w["vcov.est.fitted"] = vcovmatyhat.to_numpy()
+    else:
+        w["vcov.est.c"] = None
+        w["vcov.est.fitted"] = None
+    w["derivative.call"] = derivative
+    if derivative:
+        w["avgderivatives"] = avgderiv
+        w["var.avgderivatives"] = varavgderivmat
+        w["derivatives"] = derivmat
+    mark("finish")
+    ctx.sync()
+    T["wall"] = time.perf_counter() - t_wall0
+    for i, nm in enumerate(names):
+        T[nm] = Context.elapsed_ms(ev[i], ev[i + 1]) / 1e3
+    w["_ctx"] = ctx
+    return w
+
+
+def predict(object: BigKRLS, newdata, se_pred=False, correct_SE=True, ytest=None,
+            ctx: Optional[Context] = None) -> BigKRLSPredicted:
+    """predict.bigKRLS (R/bigKRLS.R:547-637)."""
+    if not isinstance(object, BigKRLS):
+        raise TypeError("Object not of class 'bigKRLS'")
+    if se_pred and object.get("vcov.est.c") is None:
+        raise ValueError("recompute bigKRLS object with bigKRLS(,vcov.est=TRUE) to compute standard errors")
+    ctx = ctx or object.get("_ctx") or default_context()
+    Xh = np.asarray(object["X"], dtype=np.float64)
+    bigmatrix_in = is_device_matrix(newdata) or bool(object["has.big.matrices"])   # :582
+    nd_init = _as_host_matrix(newdata)
+    nd = np.array(nd_init, dtype=np.float64)
+    if Xh.shape[1] != nd.shape[1]:
+        raise ValueError("ncol(newdata) differs from ncol(X) from fitted bigKRLS object")
+    Xmeans = Xh.mean(axis=0)                                                      # :590
+    Xsd = Xh.std(axis=0, ddof=1)                                                  # :591
+    Xs = (Xh - Xmeans) / Xsd                                                      # :593-594
+    nds = (nd - Xmeans) / Xsd                                                     # :596-597
+    Xd = ctx.from_numpy(Xs)
+    ndd = ctx.from_numpy(nds)
+    newdataK = ops.bTempKernel(ndd, Xd, object["sigma"])                          # :599
+    cd = ctx.from_numpy(np.asarray(object["coeffs"], dtype=np.float64))
+    ypred = ops.matvec(newdataK, cd).to_numpy().ravel()                           # :601
+    yv = np.asarray(object["y"], dtype=np.float64)
+    vcov_est_pred = se = None
+    if se_pred:
+        V = object["vcov.est.c"]
+        Vd = V if is_device_matrix(V) else ctx.from_numpy(np.asarray(V))
+        vy = _var(yv)
+        # var(y) * tcrossprod(newdataK %*% (vcov.est.c * (1/var(y))), newdataK)   (:608)
+        tmp = ops.gemm(False, False, newdataK, Vd, alpha=1.0 / vy)
+        vcov_est_pred = ops.gemm(False, True, tmp, newdataK, alpha=vy)
+        if correct_SE and object.get("Neffective") is not None:
+            vcov_est_pred.scale_(math.sqrt(Xh.shape[0] / float(object["Neffective"])))   # :610-611
+        se = np.sqrt(vcov_est_pred.diag())                                        # :613
+    ypred = ypred * _sd(yv) + float(yv.mean())                                    # :621
+    if not bigmatrix_in:                                                          # :623-626
+        vcov_est_pred = None if vcov_est_pred is None else vcov_est_pred.to_numpy()
+        newdataK = newdataK.to_numpy()
+    out = BigKRLSPredicted(predicted=ypred, newdata=nd_init, newdataK=newdataK, ytest=ytest)
+    out["se.pred"] = se
+    out["vcov.est.pred"] = vcov_est_pred
+    out["has.big.matrices"] = bigmatrix_in
+    return out
+
+
+def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, folds=None,
+                  ctx: Optional[Context] = None, **fit_args) -> Dict[str, object]:
+    """crossvalidate.bigKRLS (R/bigKRLS.R:1146-1336).
+
+    R partitions with set.seed(seed); sample() (:1168,1179,1232), a stream that
+    cannot be reproduced without R, so the partition can be supplied explicitly:
+    `train_idx` (0-based rows, ptesting branch) or `folds` (label 1..Kfolds per
+    row, Kfolds branch).  Without them numpy's default_rng(seed) draws one.
+    """
+    if (Kfolds is None) + (ptesting is None) != 1:
+        raise ValueError("Specify either Kfolds or ptesting but not both.")
+    Xh = _as_host_matrix(X)
+    yh = np.asarray(_as_host_matrix(y), dtype=np.float64).ravel()
+    N = Xh.shape[0]
+    marginals = fit_args.get("derivative", True)
+    rng = np.random.default_rng(seed)
+
+    def one_split(tr, te):
+        trained = bigKRLS(yh[tr], Xh[tr], ctx=ctx, **fit_args)
+        tested = predict(trained, Xh[te])
+        ytest = yh[te]
+        tested["ytest"] = ytest
+        r = {"trained": trained, "tested": tested}
+        r["pseudoR2_is"] = trained["R2"]
+        r["pseudoR2_oos"] = _cor(tested["predicted"], ytest) ** 2                 # :1195
+        r["MSE_oos"] = float(np.mean((tested["predicted"] - ytest) ** 2))         # :1196
+        r["MSE_is"] = float(np.mean((trained["yfitted"] - trained["y"]) ** 2))    # :1197
+        if marginals:
+            r["pseudoR2AME_is"] = trained["R2AME"]
+            delta = np.asarray(trained["avgderivatives"]).ravel()
+            r["MSE_AME_is"] = float(np.mean((trained["y"] - trained["X"] @ delta) ** 2))   # :1206
+            yhat_ame = Xh[te] @ delta
+            r["pseudoR2AME_oos"] = _cor(ytest, yhat_ame) ** 2                     # :1212
+            r["MSE_AME_oos"] = float(np.mean((ytest - yhat_ame) ** 2))            # :1213
+        return r
+
+    if ptesting is not None:
+        if ptesting < 0 or ptesting > 100:
+            raise ValueError("ptesting, the percentage of data to be used for validation, must be between 0 and 100.")
+        Ntesting = int(round(N * ptesting / 100.0))
+        Ntraining = N - Ntesting
+        if train_idx is None:
+            train_idx = rng.choice(N, Ntraining, replace=False)
+        tr = np.asarray(train_idx)
+        te = np.setdiff1d(np.arange(N), tr)
+        out = one_split(tr, te)
+        out.update(type="crossvalidated", seed=seed, ptesting=ptesting,
+                   indices={"train.set": tr, "test.set": te})
+        return out
+
+    if not (float(Kfolds) > 0 and float(Kfolds) % 1 == 0):
+        raise ValueError("Kfolds must be a positive integer")
+    Kfolds = int(Kfolds)
+    if folds is None:
+        perm = rng.permutation(N)
+        folds = np.empty(N, dtype=int)
+        folds[perm] = (np.arange(N) * Kfolds // N) + 1
+    folds = np.asarray(folds)
+    out: Dict[str, object] = {"type": "KfoldsCV", "Kfolds": Kfolds, "seed": seed, "folds": folds}
+    keys = ["R2_is", "R2_oos", "MSE_is", "MSE_oos"]
+    if marginals:
+        keys += ["R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos"]
+    for k in keys:
+        out[k] = []
+    for k in range(1, Kfolds + 1):
+        tr = np.nonzero(folds != k)[0]
+        te = np.nonzero(folds == k)[0]
+        r = one_split(tr, te)
+        out[f"fold_{k}"] = r
+        out["R2_is"].append(r["pseudoR2_is"])
+        out["R2_oos"].append(r["pseudoR2_oos"])
+        out["MSE_is"].append(r["MSE_is"])
+        out["MSE_oos"].append(r["MSE_oos"])
+        if marginals:
+            out["R2AME_is"].append(r["pseudoR2AME_is"])
+            out["R2AME_oos"].append(r["pseudoR2AME_oos"])
+            out["MSE_AME_is"].append(r["MSE_AME_is"])
+            out["MSE_AME_oos"].append(r["MSE_AME_oos"])
+    return out

@@ -1,0 +1,142 @@
+// Shared declarations for libbigkrls_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bigkrls.h"
+
+namespace bk {
+
+void set_error(const std::string& msg);
+
+#define BK_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      bk::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + \
+                    __FILE__ + ":" + std::to_string(__LINE__));                        \
+      return (_e == hipErrorOutOfMemory) ? BIGKRLS_ENOMEM : BIGKRLS_EHIP;              \
+    }                                                                                  \
+  } while (0)
+
+#define BK_TRY(expr)             \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != BIGKRLS_OK) return _s; \
+  } while (0)
+
+#define BK_CHECK_LAUNCH() BK_HIP(hipGetLastError())
+
+#define BK_REQUIRE(cond, msg)                       \
+  do {                                              \
+    if (!(cond)) {                                  \
+      bk::set_error(std::string("invalid argument: ") + msg); \
+      return BIGKRLS_EINVAL;                        \
+    }                                               \
+  } while (0)
+
+}  // namespace bk
+
+// The context: one device, one stream, a pool of reusable workspace slabs.
+struct bigkrls_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // workspace slots: slot i is grown on demand and reused across calls
+  static constexpr int kSlots = 32;
+  void* ws[kSlots] = {nullptr};
+  int64_t ws_bytes[kSlots] = {0};
+  // pinned host scratch for small scalar read-backs
+  double* h_pinned = nullptr;
+  int64_t h_pinned_doubles = 0;
+};
+
+namespace bk {
+
+// workspace slot ids (each caller family uses its own so nested calls never alias)
+enum Slot {
+  SLOT_GEMM_SPLITK = 0,
+  SLOT_NORMS_A = 1,
+  SLOT_NORMS_B = 2,
+  SLOT_SOLVE_PART = 3,
+  SLOT_SCALAR = 4,
+  SLOT_DERIV_B = 5,
+  SLOT_DERIV_KB = 6,
+  SLOT_DERIV_T = 7,
+  SLOT_EIG_A = 8,
+  SLOT_EIG_MISC = 9,
+  SLOT_EIG_Q0 = 10,
+  SLOT_EIG_Q1 = 11,
+  SLOT_EIG_U = 12,
+  SLOT_EIG_VEC = 13,
+  SLOT_L1_A = 14,
+  SLOT_L1_B = 15,
+  SLOT_EIG_PANEL = 16,
+  SLOT_EIG_INT = 17,
+  SLOT_EIG_BT = 18,
+  SLOT_EIG_Z = 19,
+  SLOT_EIG_DESC = 20,
+};
+
+int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
+int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out);
+
+// ---- gemm.hip -----------------------------------------------------------------
+int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha,
+         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+         int64_t ldc);
+int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
+                 int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
+                 int64_t diag_shift);
+
+// batched GEMM for the divide & conquer merges: per-problem descriptors on device
+struct GemmDesc {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int32_t m, n, k;
+  int32_t pad;
+  const int* kidx;  // optional: column gather for A (absolute column offsets from A)
+};
+int gemm_batched_nn(bigkrls_ctx* ctx, const GemmDesc* d_descs, int n_batch, int max_m, int max_n);
+
+// ---- vecops.hip ---------------------------------------------------------------
+int gemv(bigkrls_ctx* ctx, int trans, int64_t m, int64_t n, double alpha, const double* A,
+         int64_t lda, const double* x, double beta, double* y);
+int dot_host(bigkrls_ctx* ctx, int64_t n, const double* x, const double* y, double* h_out);
+int multdiag(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t k, int64_t lda,
+             const double* diag, double* out, int64_t ldo);
+int diag_extract(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, double* out);
+int scale(bigkrls_ctx* ctx, int64_t n, double alpha, double* x);
+int row_sqnorms(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t p, int64_t lda, double* out);
+int copy_matrix(bigkrls_ctx* ctx, const double* A, int64_t m, int64_t n, int64_t lda, double* B,
+                int64_t ldb);
+
+// ---- solveforc.hip ------------------------------------------------------------
+int qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq, const double* y,
+        double* a);
+int solveforc(bigkrls_ctx* ctx, const double* Q, int64_t n_rows, int64_t k, int64_t ldq,
+              const double* d, const double* a, double lambda, double* c, double* h_Le);
+int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, double* U);
+int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
+                  const double* d, const double* a, const double* h_vals_all, int64_t n_vals,
+                  double L, double U, double tol, double* h_lambda, int64_t* h_nprobes,
+                  double* h_trace, int64_t max_trace);
+
+// ---- deriv.hip ----------------------------------------------------------------
+int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
+               int64_t row0, const double* X, int64_t p, int64_t ldx, const int32_t* h_is_binary,
+               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds);
+int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
+              const double* wv, const double* S, int64_t p, int64_t lds, const double* h_scale,
+              double* h_var);
+
+// ---- eigen.hip ----------------------------------------------------------------
+int eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals, double* vals,
+          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs);
+
+}  // namespace bk

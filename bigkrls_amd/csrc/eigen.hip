@@ -1,0 +1,965 @@
+// Symmetric eigendecomposition on one MI355X, fp64, written from scratch.
+//
+// Replaces src/eigen.cpp:13-30 (arma::eig_sym -> LAPACK dsyevd; arma::eigs_sym ->
+// ARPACK) and the truncation logic of bEigen (R/bigKRLS_Rcpp_functions.R:173-199).
+//
+//   phase 1  Householder tridiagonalisation, blocked (panel of 64 reflectors):
+//            per column a coalesced wave-reduced symv over the trailing matrix
+//            (HBM-bound half), per panel one rank-128 fp64 MFMA update
+//            A22 -= [V W][W V]' (MFMA-bound half).
+//   phase 2  Cuppen / Gu-Eisenstat divide & conquer on the tridiagonal matrix,
+//            torn down to 1 x 1 leaves. Host does the O(n) deflation scan per
+//            merge; the device does rank-one rotations, the secular equation
+//            (one wave per root, bracketed geometric bisection on the shifted
+//            variable, so every pole-root difference has full relative accuracy),
+//            the Loewner re-derivation of z, and the eigenvector update as
+//            batched fp64 MFMA GEMMs with gathered columns. Only the eigenvector
+//            columns that will be kept (lastkeeper) are formed at the last merge.
+//   phase 3  back-transform Z <- (I - V T V') Z per reflector panel (compact WY),
+//            three fp64 MFMA GEMMs per panel.
+//
+// The eigenvalues are returned descending, the eigenvectors in matching columns
+// (src/eigen.cpp:28-29). Signs are arbitrary (the reference flips them and never
+// returns them to the user: R/bigKRLS_Rcpp_functions.R:186, quirk Q9).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace bk {
+namespace {
+
+constexpr int TRD_NB = 64;
+constexpr double DEPS = 2.220446049250313e-16;
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;  // every lane holds the identical total
+}
+__device__ __forceinline__ double wprod(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double bsum256(double v, double* sh) {
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+// =============================================================================
+// phase 1: tridiagonalisation
+// P1 = [V | Wm], P2 = [Wm | V], each n x 2*pw (ld n); column k of V at P1[:,k],
+// column k of Wm at P1[:,pw+k].
+// =============================================================================
+
+// K1: finalise w_{i-1}, bring column c up to date, d[c], partial ||x[1:]||^2
+__global__ __launch_bounds__(256) void trd_k1(double* __restrict__ W, int n, int c, int i, int pw,
+                                              double* __restrict__ P1, double* __restrict__ P2,
+                                              const double* __restrict__ part2, int np2,
+                                              const double* __restrict__ tau,
+                                              double* __restrict__ d, double* __restrict__ part1) {
+  __shared__ double sV[TRD_NB], sW[TRD_NB], sh[4];
+  __shared__ double s_alpha2;
+  const int tid = threadIdx.x;
+  const int r = c + blockIdx.x * 256 + tid;
+  const int64_t N = n;
+  double a = 0.0;
+  if (i > 0) {
+    if (tid == 0) {
+      double s = 0.0;
+      for (int q = 0; q < np2; ++q) s += part2[q];
+      s_alpha2 = -0.5 * tau[c - 1] * s;
+    }
+    __syncthreads();
+    const double alpha2 = s_alpha2;
+    double v_last = 0.0, w_last = 0.0;
+    if (r < n) {
+      v_last = P1[r + (int64_t)(i - 1) * N];
+      w_last = P1[r + (int64_t)(pw + i - 1) * N] + alpha2 * v_last;
+      if (r > c) {  // row c of this column is never read again: leave it (no race with readers)
+        P1[r + (int64_t)(pw + i - 1) * N] = w_last;
+        P2[r + (int64_t)(i - 1) * N] = w_last;
+      }
+    }
+    if (tid < i) {
+      sV[tid] = P1[c + (int64_t)tid * N];
+      sW[tid] = (tid == i - 1)
+                    ? P1[c + (int64_t)(pw + i - 1) * N] + alpha2 * P1[c + (int64_t)(i - 1) * N]
+                    : P1[c + (int64_t)(pw + tid) * N];
+    }
+    __syncthreads();
+    if (r < n) {
+      a = W[r + (int64_t)c * N];
+      for (int k = 0; k < i - 1; ++k)
+        a -= P1[r + (int64_t)k * N] * sW[k] + P1[r + (int64_t)(pw + k) * N] * sV[k];
+      a -= v_last * sW[i - 1] + w_last * sV[i - 1];
+      W[r + (int64_t)c * N] = a;
+    }
+  } else if (r < n) {
+    a = W[r + (int64_t)c * N];
+  }
+  if (r == c) d[c] = a;
+  double ss = (r < n && r >= c + 2) ? a * a : 0.0;
+  ss = bsum256(ss, sh);
+  if (tid == 0) part1[blockIdx.x] = ss;
+}
+
+// K2: Householder scalars (recomputed identically by every block), y = A22' v,
+// panel dots t1 = Wm' v, t2 = V' v, and v stored into the panel.
+__global__ __launch_bounds__(256) void trd_k2(const double* __restrict__ W, int n, int c, int i,
+                                              int pw, double* __restrict__ P1,
+                                              double* __restrict__ P2,
+                                              const double* __restrict__ part1, int np1,
+                                              double* __restrict__ y, double* __restrict__ tvec,
+                                              double* __restrict__ e, double* __restrict__ tau) {
+  __shared__ double s_scale;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t N = n;
+  const int L = n - c - 1;
+  const double* x = W + (c + 1) + (int64_t)c * N;
+  if (tid == 0) {
+    double ss = 0.0;
+    for (int q = 0; q < np1; ++q) ss += part1[q];
+    const double alpha = x[0];
+    double beta, t, sc;
+    if (ss == 0.0) {
+      beta = alpha; t = 0.0; sc = 0.0;
+    } else {
+      beta = -copysign(hypot(alpha, sqrt(ss)), alpha);
+      t = (beta - alpha) / beta;
+      sc = 1.0 / (alpha - beta);
+    }
+    s_scale = sc;
+    if (blockIdx.x == 0) { e[c] = beta; tau[c] = t; }
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  // four columns per wave
+  const int q0 = (blockIdx.x * 4 + wave) * 4;
+  const int total = L + 2 * i;
+  const double* ptr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = q0 + u;
+    if (q < L) ptr[u] = W + (c + 1) + (int64_t)(c + 1 + q) * N;
+    else if (q < L + i) ptr[u] = P1 + (c + 1) + (int64_t)(pw + (q - L)) * N;
+    else if (q < total) ptr[u] = P1 + (c + 1) + (int64_t)(q - L - i) * N;
+    else ptr[u] = nullptr;
+  }
+  if (q0 < total) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = lane; r < L; r += 64) {
+      const double v = (r == 0) ? 1.0 : x[r] * scale;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ptr[u]) acc[u] += ptr[u][r] * v;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double s = wsum(acc[u]);
+      const int q = q0 + u;
+      if (lane == 0 && q < total) {
+        if (q < L) y[q] = s;
+        else tvec[q - L] = s;   // [0,i): Wm'v ; [i,2i): V'v
+      }
+    }
+  }
+  // store v into the panel (first ceil(L/256) blocks)
+  const int r = blockIdx.x * 256 + tid;
+  if (r < L) {
+    const double v = (r == 0) ? 1.0 : x[r] * scale;
+    P1[(c + 1 + r) + (int64_t)i * N] = v;
+    P2[(c + 1 + r) + (int64_t)(pw + i) * N] = v;
+  }
+}
+
+// K3: w~ = tau (y - V (Wm'v) - Wm (V'v)), partial w~'v, reflector stored in place
+__global__ __launch_bounds__(256) void trd_k3(double* __restrict__ W, int n, int c, int i, int pw,
+                                              double* __restrict__ P1, double* __restrict__ P2,
+                                              const double* __restrict__ y,
+                                              const double* __restrict__ tvec,
+                                              const double* __restrict__ tau,
+                                              double* __restrict__ part2) {
+  __shared__ double st1[TRD_NB], st2[TRD_NB], sh[4];
+  const int tid = threadIdx.x;
+  const int64_t N = n;
+  const int L = n - c - 1;
+  if (tid < i) {
+    st1[tid] = tvec[tid];
+    st2[tid] = tvec[i + tid];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + tid;
+  double pv = 0.0;
+  if (r < L) {
+    const int64_t row = c + 1 + r;
+    const double v = P1[row + (int64_t)i * N];
+    double s = y[r];
+    for (int k = 0; k < i; ++k)
+      s -= P1[row + (int64_t)k * N] * st1[k] + P1[row + (int64_t)(pw + k) * N] * st2[k];
+    const double wt = tau[c] * s;
+    P1[row + (int64_t)(pw + i) * N] = wt;
+    P2[row + (int64_t)i * N] = wt;
+    W[row + (int64_t)c * N] = v;
+    pv = wt * v;
+  }
+  pv = bsum256(pv, sh);
+  if (tid == 0) part2[blockIdx.x] = pv;
+}
+
+// finalise the last w column of a panel (rows >= row_begin)
+__global__ __launch_bounds__(256) void trd_fin(int n, int c, int i, int pw,
+                                               double* __restrict__ P1, double* __restrict__ P2,
+                                               const double* __restrict__ part2, int np2,
+                                               const double* __restrict__ tau) {
+  __shared__ double s_alpha2;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int q = 0; q < np2; ++q) s += part2[q];
+    s_alpha2 = -0.5 * tau[c] * s;
+  }
+  __syncthreads();
+  const int64_t N = n;
+  const int r = c + 1 + blockIdx.x * 256 + threadIdx.x;
+  if (r < n) {
+    const double wf = P1[r + (int64_t)(pw + i) * N] + s_alpha2 * P1[r + (int64_t)i * N];
+    P1[r + (int64_t)(pw + i) * N] = wf;
+    P2[r + (int64_t)i * N] = wf;
+  }
+}
+
+int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, double* tau,
+                   double* P1, double* P2, double* scratch /* y[n] + tvec[2nb] + part1 + part2 */) {
+  const int maxb = (n + 255) / 256 + 1;
+  double* y = scratch;
+  double* tvec = y + n;
+  double* part1 = tvec + 2 * TRD_NB;
+  double* part2 = part1 + maxb;
+  hipStream_t st = ctx->stream;
+  const int64_t N = n;
+  for (int j0 = 0; j0 < n - 1; j0 += TRD_NB) {
+    const int pw = std::min(TRD_NB, n - 1 - j0);
+    int np2 = 0;
+    for (int i = 0; i < pw; ++i) {
+      const int c = j0 + i;
+      const int nb1 = (n - c + 255) / 256;
+      hipLaunchKernelGGL(trd_k1, dim3(nb1), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
+                         (const double*)part2, np2, (const double*)tau, d, part1);
+      const int L = n - c - 1;
+      const int nb2 = (L + 2 * i + 15) / 16;
+      hipLaunchKernelGGL(trd_k2, dim3(nb2), dim3(256), 0, st, (const double*)W, n, c, i, pw, P1, P2,
+                         (const double*)part1, nb1, y, tvec, e, tau);
+      const int nb3 = (L + 255) / 256;
+      hipLaunchKernelGGL(trd_k3, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
+                         (const double*)y, (const double*)tvec, (const double*)tau, part2);
+      np2 = nb3;
+    }
+    BK_CHECK_LAUNCH();
+    const int cl = j0 + pw - 1;
+    const int j1 = j0 + pw;
+    const int nbf = (n - cl - 1 + 255) / 256;
+    hipLaunchKernelGGL(trd_fin, dim3(nbf), dim3(256), 0, st, n, cl, pw - 1, pw, P1, P2,
+                       (const double*)part2, np2, (const double*)tau);
+    BK_CHECK_LAUNCH();
+    const int64_t mt = n - j1;
+    BK_TRY(gemm(ctx, 0, 1, mt, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, 1.0, W + j1 + (int64_t)j1 * N,
+                N));
+  }
+  BK_HIP(hipMemcpyAsync(d + (n - 1), W + (int64_t)(n - 1) * N + (n - 1), sizeof(double),
+                        hipMemcpyDeviceToDevice, st));
+  return BIGKRLS_OK;
+}
+
+// =============================================================================
+// phase 2: divide & conquer
+// =============================================================================
+struct MergeDesc {
+  int s, n1, m, K;
+  int k1, k2, k3, Kneed;
+  int rot_off, nrot, ndef, pad;
+  double rho;
+};
+
+__global__ void dc_init_identity(double* __restrict__ Q, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Q[(int64_t)i * n + i] = 1.0;
+}
+
+// z[s+t] = last row of the left child (t < n1) / first row of the right child
+__global__ void dc_gather_z(const MergeDesc* __restrict__ descs, const double* __restrict__ Q,
+                            int64_t ld, double* __restrict__ z) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.m) return;
+  const int row = (t < d.n1) ? d.s + d.n1 - 1 : d.s + d.n1;
+  z[d.s + t] = Q[row + (int64_t)(d.s + t) * ld];
+}
+
+// apply the deflation rotations of one merge, in order, to every row
+__global__ void dc_rotate(const MergeDesc* __restrict__ descs, const int* __restrict__ merge_ids,
+                          const int* __restrict__ ra, const int* __restrict__ rb,
+                          const double* __restrict__ rc, const double* __restrict__ rs,
+                          double* __restrict__ Q, int64_t ld) {
+  const MergeDesc d = descs[merge_ids[blockIdx.y]];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= d.m) return;
+  double* q = Q + (d.s + r) + (int64_t)d.s * ld;
+  for (int t = 0; t < d.nrot; ++t) {
+    const int a = ra[d.rot_off + t], b = rb[d.rot_off + t];
+    const double c = rc[d.rot_off + t], s = rs[d.rot_off + t];
+    const double xa = q[(int64_t)a * ld], xb = q[(int64_t)b * ld];
+    q[(int64_t)a * ld] = c * xa + s * xb;
+    q[(int64_t)b * ld] = c * xb - s * xa;
+  }
+}
+
+// One wave per root of 1 + rho * sum_i w_i^2/(dlam_i - lambda) = 0.
+// Writes lambda_j and delta_ij = dlam_i - lambda_j (row = rowpos(i), col = cpos(j)).
+__global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ descs,
+                                                  const double* __restrict__ dlam,
+                                                  const double* __restrict__ w,
+                                                  const int* __restrict__ rowpos,
+                                                  const int* __restrict__ cpos,
+                                                  double* __restrict__ U, int64_t ld,
+                                                  double* __restrict__ lam) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = d.K;
+  if (j >= K) return;
+  const int base = d.s;
+  const double* dl = dlam + base;
+  const double* ww = w + base;
+  const double rho = d.rho;
+  int org;
+  double sgn, lo, hi;
+  if (j < K - 1) {
+    const double dj = dl[j], dj1 = dl[j + 1];
+    const double half = 0.5 * (dj1 - dj);
+    double g = 0.0, rl = 0.0, rr = 0.0;
+    for (int i = lane; i < K; i += 64) {
+      const double w2 = ww[i] * ww[i];
+      g += w2 / ((dl[i] - dj) - half);
+      if (i > j) rr += w2 / ((dl[i] - dj) - half);
+      else rl += w2 / ((dj1 - dl[i]) - half);
+    }
+    g = 1.0 + rho * wsum(g);
+    rr = wsum(rr);
+    rl = wsum(rl);
+    hi = half;
+    if (g >= 0.0) {
+      org = j; sgn = 1.0;
+      const double R = 1.0 + rho * rr;
+      lo = rho * ww[j] * ww[j] / R;
+    } else {
+      org = j + 1; sgn = -1.0;
+      const double R = -1.0 + rho * rl;
+      lo = (R > 0.0) ? rho * ww[j + 1] * ww[j + 1] / R : 0.0;
+    }
+  } else {
+    org = j; sgn = 1.0;
+    double s2 = 0.0;
+    for (int i = lane; i < K; i += 64) s2 += ww[i] * ww[i];
+    s2 = wsum(s2);
+    hi = rho * s2 * (1.0 + 8.0 * DEPS);
+    lo = rho * ww[j] * ww[j];
+  }
+  lo = fmin(lo, hi) * (1.0 - 8.0 * DEPS);
+  if (!(lo > 0.0)) lo = hi * 1e-300;
+  const double dorg = dl[org];
+  for (int it = 0; it < 400; ++it) {
+    if (!(hi > lo)) break;
+    const double mid = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
+    if (!(mid > lo) || !(mid < hi)) break;
+    const double tau = sgn * mid;
+    double g = 0.0;
+    for (int i = lane; i < K; i += 64) g += ww[i] * ww[i] / ((dl[i] - dorg) - tau);
+    g = 1.0 + rho * wsum(g);
+    const bool pos = (g >= 0.0);
+    if (sgn > 0.0) { if (pos) hi = mid; else lo = mid; }
+    else           { if (pos) lo = mid; else hi = mid; }
+  }
+  const double tau = sgn * 0.5 * (lo + hi);
+  if (lane == 0) lam[base + j] = dorg + tau;
+  const int64_t col = base + cpos[base + j];
+  for (int i = lane; i < K; i += 64)
+    U[(base + rowpos[base + i]) + col * ld] = (dl[i] - dorg) - tau;
+}
+
+// Loewner: zhat_i = sign(w_i) sqrt| delta_ii * prod_{j != i} delta_ij / (dlam_i - dlam_j) |
+__global__ __launch_bounds__(256) void dc_zhat(const MergeDesc* __restrict__ descs,
+                                               const double* __restrict__ dlam,
+                                               const double* __restrict__ w,
+                                               const int* __restrict__ pole_of_row,
+                                               const int* __restrict__ cpos,
+                                               const double* __restrict__ U, int64_t ld,
+                                               double* __restrict__ zhat) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = d.K;
+  if (r >= K) return;
+  const int base = d.s;
+  const int i = pole_of_row[base + r];
+  const double di = dlam[base + i];
+  double p = 1.0;
+  for (int j = lane; j < K; j += 64) {
+    const double delta = U[(base + r) + (int64_t)(base + cpos[base + j]) * ld];
+    p *= (j == i) ? delta : delta / (di - dlam[base + j]);
+  }
+  p = wprod(p);
+  if (lane == 0) zhat[base + r] = copysign(sqrt(fabs(p)), w[base + i]);
+}
+
+// U[:,cp] = normalised zhat / delta[:,cp]   (one block per kept column)
+__global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ descs,
+                                                  const double* __restrict__ zhat,
+                                                  double* __restrict__ U, int64_t ld) {
+  __shared__ double sh[4];
+  const MergeDesc d = descs[blockIdx.y];
+  const int cp = blockIdx.x;
+  if (cp >= d.Kneed) return;
+  const int base = d.s;
+  double* u = U + base + (int64_t)(base + cp) * ld;
+  const double* zh = zhat + base;
+  double ss = 0.0;
+  for (int r = threadIdx.x; r < d.K; r += 256) {
+    const double v = zh[r] / u[r];
+    u[r] = v;
+    ss += v * v;
+  }
+  ss = bsum256(ss, sh);
+  const double inv = 1.0 / sqrt(ss);
+  for (int r = threadIdx.x; r < d.K; r += 256) u[r] *= inv;
+}
+
+__global__ void dc_copy_deflated(const MergeDesc* __restrict__ descs,
+                                 const int* __restrict__ defsrc, const int* __restrict__ defdst,
+                                 const double* __restrict__ Qc, double* __restrict__ Qn,
+                                 int64_t ld) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int idx = blockIdx.x;
+  if (idx >= d.ndef) return;
+  const int src = defsrc[d.s + idx], dst = defdst[d.s + idx];
+  const double* a = Qc + d.s + (int64_t)(d.s + src) * ld;
+  double* b = Qn + d.s + (int64_t)(d.s + dst) * ld;
+  for (int r = threadIdx.x; r < d.m; r += blockDim.x) b[r] = a[r];
+}
+
+__global__ void gather_cols(int n, int nv, const int* __restrict__ src, const double* __restrict__ Q,
+                            int64_t ldq, double* __restrict__ Z, int64_t ldz) {
+  const int64_t total = (int64_t)n * nv;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % n), c = (int)(e / n);
+    Z[r + (int64_t)c * ldz] = Q[r + (int64_t)src[c] * ldq];
+  }
+}
+
+struct Node {
+  int s, m, left, right, depth;
+  std::vector<double> dv;  // eigenvalue of storage column s+t
+};
+
+// host side of one merge (LAPACK dlaed2's scan, re-derived): fills the packed
+// per-level arrays at offset s.
+struct LevelArrays {
+  std::vector<double> dlam, w, rc, rs;
+  std::vector<int> rowpos, pole_of_row, srccol, cpos, defsrc, defdst, ra, rb;
+};
+
+void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, MergeDesc& md,
+                LevelArrays& A, std::vector<double>& defvals, std::vector<int>& types_out) {
+  const int n1 = L.m, n2 = R.m, m = n1 + n2, s = L.s;
+  const double theta = (ecut >= 0.0) ? 1.0 : -1.0;
+  const double rho = 2.0 * std::fabs(ecut);
+  std::vector<double> z(m), D(m);
+  const double isq2 = 1.0 / std::sqrt(2.0);
+  for (int t = 0; t < m; ++t) {
+    z[t] = zraw[s + t] * ((t < n1) ? 1.0 : theta) * isq2;
+    D[t] = (t < n1) ? L.dv[t] : R.dv[t - n1];
+  }
+  std::vector<int> order(m);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
+  double dmax = 0.0, zmax = 0.0;
+  for (int t = 0; t < m; ++t) {
+    dmax = std::max(dmax, std::fabs(D[t]));
+    zmax = std::max(zmax, std::fabs(z[t]));
+  }
+  const double tol = 8.0 * DEPS * std::max(dmax, zmax);
+  std::vector<int> typ(m);
+  for (int t = 0; t < m; ++t) typ[t] = (t < n1) ? 1 : 3;
+  std::vector<int> nd, df;
+  md.s = s; md.n1 = n1; md.m = m; md.rho = rho;
+  md.rot_off = (int)A.ra.size(); md.nrot = 0;
+  if (rho * zmax <= tol) {
+    for (int t : order) df.push_back(t);
+  } else {
+    int pj = -1;
+    for (int t : order) {
+      if (rho * std::fabs(z[t]) <= tol) { df.push_back(t); typ[t] = 4; continue; }
+      if (pj < 0) { pj = t; continue; }
+      double sv = z[pj], cv = z[t];
+      const double tau = std::hypot(cv, sv);
+      const double tt = D[t] - D[pj];
+      cv /= tau; sv = -sv / tau;
+      if (std::fabs(tt * cv * sv) <= tol) {
+        z[t] = tau; z[pj] = 0.0;
+        if (typ[t] != typ[pj]) typ[t] = 2;
+        typ[pj] = 4;
+        A.ra.push_back(pj); A.rb.push_back(t); A.rc.push_back(cv); A.rs.push_back(sv);
+        md.nrot++;
+        const double tmp = D[pj] * cv * cv + D[t] * sv * sv;
+        D[t] = D[pj] * sv * sv + D[t] * cv * cv;
+        D[pj] = tmp;
+        df.push_back(pj);
+        pj = t;
+      } else {
+        nd.push_back(pj);
+        pj = t;
+      }
+    }
+    if (pj >= 0) nd.push_back(pj);
+  }
+  const int K = (int)nd.size();
+  md.K = K; md.Kneed = K; md.ndef = m - K;
+  // poles ascending = nd order; rows of U grouped by column type 1,2,3
+  int k1 = 0, k2 = 0, k3 = 0;
+  for (int t : nd) { if (typ[t] == 1) ++k1; else if (typ[t] == 2) ++k2; else ++k3; }
+  md.k1 = k1; md.k2 = k2; md.k3 = k3;
+  int p1 = 0, p2 = k1, p3 = k1 + k2;
+  for (int i = 0; i < K; ++i) {
+    const int t = nd[i];
+    A.dlam[s + i] = D[t];
+    A.w[s + i] = z[t];
+    int row = (typ[t] == 1) ? p1++ : (typ[t] == 2) ? p2++ : p3++;
+    A.rowpos[s + i] = row;
+    A.pole_of_row[s + row] = i;
+    A.srccol[s + row] = t;
+    A.cpos[s + i] = i;
+  }
+  defvals.resize(m - K);
+  for (int q = 0; q < m - K; ++q) {
+    A.defsrc[s + q] = df[q];
+    A.defdst[s + q] = K + q;
+    defvals[q] = D[df[q]];
+  }
+  types_out = typ;
+}
+
+int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
+                   const std::vector<double>& he, double* Q0, double* Q1, double* U,
+                   int64_t n_vals, int64_t n_vecs_max, double keep_thresh,
+                   std::vector<double>& vals_desc, std::vector<int>& src_cols, double** Qfinal) {
+  hipStream_t st = ctx->stream;
+  const int64_t N = n;
+  // ---- tree -----------------------------------------------------------------
+  std::vector<Node> nodes;
+  nodes.reserve(2 * n);
+  std::vector<double> dadj = hd;
+  {
+    struct Item { int s, m, depth, parent, side; };
+    std::vector<Item> stack;
+    stack.push_back({0, n, 0, -1, 0});
+    while (!stack.empty()) {
+      Item it = stack.back();
+      stack.pop_back();
+      Node nd;
+      nd.s = it.s; nd.m = it.m; nd.left = nd.right = -1; nd.depth = it.depth;
+      const int id = (int)nodes.size();
+      nodes.push_back(nd);
+      if (it.parent >= 0) {
+        if (it.side == 0) nodes[it.parent].left = id; else nodes[it.parent].right = id;
+      }
+      if (it.m > 1) {
+        const int n1 = it.m / 2;
+        const int cut = it.s + n1 - 1;  // e[cut] couples rows cut, cut+1
+        const double rho = std::fabs(he[cut]);
+        dadj[cut] -= rho;
+        dadj[cut + 1] -= rho;
+        stack.push_back({it.s, n1, it.depth + 1, id, 0});
+        stack.push_back({it.s + n1, it.m - n1, it.depth + 1, id, 1});
+      }
+    }
+  }
+  int maxdepth = 0;
+  for (auto& nd : nodes) {
+    maxdepth = std::max(maxdepth, nd.depth);
+    if (nd.m == 1) nd.dv.assign(1, dadj[nd.s]);
+  }
+  std::vector<std::vector<int>> by_depth(maxdepth + 1);
+  for (int id = 0; id < (int)nodes.size(); ++id)
+    if (nodes[id].m > 1) by_depth[nodes[id].depth].push_back(id);
+
+  // ---- device state ---------------------------------------------------------
+  BK_HIP(hipMemsetAsync(Q0, 0, (size_t)N * N * sizeof(double), st));
+  BK_HIP(hipMemsetAsync(Q1, 0, (size_t)N * N * sizeof(double), st));
+  hipLaunchKernelGGL(dc_init_identity, dim3((n + 255) / 256), dim3(256), 0, st, Q0, n);
+  hipLaunchKernelGGL(dc_init_identity, dim3((n + 255) / 256), dim3(256), 0, st, Q1, n);
+  BK_CHECK_LAUNCH();
+  // double arrays: z, dlam, w, lam, zhat, rc, rs  (7n) ; int arrays: 8n ; descs
+  void* pd = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_EIG_MISC, (int64_t)8 * n * sizeof(double), &pd));
+  double* d_z = (double*)pd;
+  double* d_dlam = d_z + n;
+  double* d_w = d_dlam + n;
+  double* d_lam = d_w + n;
+  double* d_zhat = d_lam + n;
+  double* d_rc = d_zhat + n;
+  double* d_rs = d_rc + n;
+  void* pi = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)10 * n * sizeof(int), &pi));
+  int* d_rowpos = (int*)pi;
+  int* d_pole = d_rowpos + n;
+  int* d_srccol = d_pole + n;
+  int* d_cpos = d_srccol + n;
+  int* d_defsrc = d_cpos + n;
+  int* d_defdst = d_defsrc + n;
+  int* d_ra = d_defdst + n;
+  int* d_rb = d_ra + n;
+  int* d_rotids = d_rb + n;
+  const int max_merges = n / 2 + 1;
+  void* pdesc = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_EIG_DESC,
+                (int64_t)max_merges * (sizeof(MergeDesc) + 2 * sizeof(GemmDesc)), &pdesc));
+  MergeDesc* d_descs = (MergeDesc*)pdesc;
+  GemmDesc* d_gdescs = (GemmDesc*)(d_descs + max_merges);
+
+  double* Qc = Q0;
+  double* Qn = Q1;
+  std::vector<double> hz(n), hlam(n);
+  LevelArrays A;
+  A.dlam.resize(n); A.w.resize(n);
+  A.rowpos.resize(n); A.pole_of_row.resize(n); A.srccol.resize(n); A.cpos.resize(n);
+  A.defsrc.resize(n); A.defdst.resize(n);
+
+  int64_t nv_final = 0;
+  for (int depth = maxdepth - 1; depth >= 0; --depth) {
+    const std::vector<int>& ids = by_depth[depth];
+    const int nm = (int)ids.size();
+    if (nm == 0) continue;
+    std::vector<MergeDesc> descs(nm);
+    int max_m = 0;
+    for (int q = 0; q < nm; ++q) {
+      const Node& P = nodes[ids[q]];
+      descs[q] = MergeDesc{};
+      descs[q].s = P.s; descs[q].n1 = nodes[P.left].m; descs[q].m = P.m;
+      max_m = std::max(max_m, P.m);
+    }
+    BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    for (int b0 = 0; b0 < nm; b0 += 65535) {
+      const int nb = std::min(65535, nm - b0);
+      hipLaunchKernelGGL(dc_gather_z, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
+                         (const MergeDesc*)(d_descs + b0), (const double*)Qc, N, d_z);
+    }
+    BK_CHECK_LAUNCH();
+    BK_HIP(hipMemcpyAsync(hz.data(), d_z, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    BK_HIP(hipStreamSynchronize(st));
+
+    // host deflation scans
+    A.ra.clear(); A.rb.clear(); A.rc.clear(); A.rs.clear();
+    std::vector<std::vector<double>> defvals(nm);
+    std::vector<int> rot_merges;
+    int maxK = 0, max_ndef = 0;
+    std::vector<int> typ;
+    for (int q = 0; q < nm; ++q) {
+      const Node& P = nodes[ids[q]];
+      const Node& Ln = nodes[P.left];
+      const Node& Rn = nodes[P.right];
+      const int cut = P.s + Ln.m - 1;
+      host_merge(Ln, Rn, he[cut], hz.data(), descs[q], A, defvals[q], typ);
+      if (descs[q].nrot > 0) rot_merges.push_back(q);
+      maxK = std::max(maxK, descs[q].K);
+      max_ndef = std::max(max_ndef, descs[q].ndef);
+    }
+    const bool is_root = (depth == 0);
+    if (is_root) {
+      // store roots in descending order so that the kept ones are a prefix
+      const int K = descs[0].K, s = descs[0].s;
+      for (int j = 0; j < K; ++j) A.cpos[s + j] = K - 1 - j;
+    }
+    BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_dlam, A.dlam.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_w, A.w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_rowpos, A.rowpos.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_pole, A.pole_of_row.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_srccol, A.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_cpos, A.cpos.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_defsrc, A.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_defdst, A.defdst.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    const int nrot_total = (int)A.ra.size();
+    if (nrot_total > 0) {
+      BK_HIP(hipMemcpyAsync(d_ra, A.ra.data(), nrot_total * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rb, A.rb.data(), nrot_total * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rc, A.rc.data(), nrot_total * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rs, A.rs.data(), nrot_total * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rotids, rot_merges.data(), rot_merges.size() * sizeof(int),
+                            hipMemcpyHostToDevice, st));
+      const int nrm = (int)rot_merges.size();
+      for (int b0 = 0; b0 < nrm; b0 += 65535) {
+        const int nb = std::min(65535, nrm - b0);
+        hipLaunchKernelGGL(dc_rotate, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
+                           (const MergeDesc*)d_descs, (const int*)(d_rotids + b0), (const int*)d_ra,
+                           (const int*)d_rb, (const double*)d_rc, (const double*)d_rs, Qc, N);
+      }
+      BK_CHECK_LAUNCH();
+    }
+    if (maxK > 0) {
+      for (int b0 = 0; b0 < nm; b0 += 65535) {
+        const int nb = std::min(65535, nm - b0);
+        hipLaunchKernelGGL(dc_secular, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
+                           (const MergeDesc*)(d_descs + b0), (const double*)d_dlam,
+                           (const double*)d_w, (const int*)d_rowpos, (const int*)d_cpos, U, N, d_lam);
+        hipLaunchKernelGGL(dc_zhat, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
+                           (const MergeDesc*)(d_descs + b0), (const double*)d_dlam,
+                           (const double*)d_w, (const int*)d_pole, (const int*)d_cpos,
+                           (const double*)U, N, d_zhat);
+      }
+      BK_CHECK_LAUNCH();
+      BK_HIP(hipMemcpyAsync(hlam.data(), d_lam, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    BK_HIP(hipStreamSynchronize(st));
+    // new eigenvalue lists in storage order
+    for (int q = 0; q < nm; ++q) {
+      Node& P = nodes[ids[q]];
+      const int K = descs[q].K, s = P.s;
+      P.dv.assign(P.m, 0.0);
+      for (int j = 0; j < K; ++j) {
+        const double lv = hlam[s + j];
+        if (!std::isfinite(lv)) {
+          set_error("eigen: secular equation produced a non-finite root");
+          return BIGKRLS_ENOCONV;
+        }
+        P.dv[A.cpos[s + j]] = lv;
+      }
+      for (int t = 0; t < P.m - K; ++t) P.dv[K + t] = defvals[q][t];
+      nodes[P.left].dv.clear(); nodes[P.left].dv.shrink_to_fit();
+      nodes[P.right].dv.clear(); nodes[P.right].dv.shrink_to_fit();
+    }
+    if (is_root) {
+      const Node& P = nodes[ids[0]];
+      std::vector<int> ord(n);
+      std::iota(ord.begin(), ord.end(), 0);
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.dv[a] > P.dv[b]; });
+      vals_desc.resize(n);
+      for (int t = 0; t < n; ++t) vals_desc[t] = P.dv[ord[t]];
+      int64_t nv = n_vecs_max;
+      if (keep_thresh >= 0.0) {
+        int64_t keep = 0;
+        const double thr = keep_thresh * vals_desc[0];
+        for (int64_t t = 0; t < n_vals; ++t)
+          if (vals_desc[t] >= thr) keep = t + 1;   // max(which(values >= eigtrunc*values[1]))
+        nv = std::min<int64_t>(nv, std::max<int64_t>(keep, 1));
+      }
+      nv_final = nv;
+      src_cols.resize(nv);
+      int kneed = 0;
+      for (int64_t t = 0; t < nv; ++t) {
+        src_cols[t] = ord[t];
+        if (ord[t] < descs[0].K) ++kneed;
+      }
+      descs[0].Kneed = kneed;
+      BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    }
+    // eigenvector update
+    int maxKneed = 0;
+    for (int q = 0; q < nm; ++q) maxKneed = std::max(maxKneed, descs[q].Kneed);
+    if (maxKneed > 0) {
+      for (int b0 = 0; b0 < nm; b0 += 65535) {
+        const int nb = std::min(65535, nm - b0);
+        hipLaunchKernelGGL(dc_vectors, dim3(maxKneed, nb), dim3(256), 0, st,
+                           (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, U, N);
+      }
+      BK_CHECK_LAUNCH();
+      std::vector<GemmDesc> gd;
+      gd.reserve(2 * nm);
+      int gm = 0, gn = 0;
+      for (int q = 0; q < nm; ++q) {
+        const MergeDesc& md = descs[q];
+        if (md.Kneed <= 0) continue;
+        const int k12 = md.k1 + md.k2, k23 = md.k2 + md.k3;
+        const int n2 = md.m - md.n1;
+        const int64_t o = md.s + (int64_t)md.s * N;
+        // rows of the left child that no kept column touches must still be written
+        GemmDesc g1{};
+        g1.A = Qc + o; g1.B = U + o; g1.C = Qn + o;
+        g1.lda = N; g1.ldb = N; g1.ldc = N;
+        g1.m = md.n1; g1.n = md.Kneed; g1.k = k12; g1.kidx = d_srccol + md.s;
+        gd.push_back(g1);
+        GemmDesc g2{};
+        g2.A = Qc + o + md.n1; g2.B = U + o + md.k1; g2.C = Qn + o + md.n1;
+        g2.lda = N; g2.ldb = N; g2.ldc = N;
+        g2.m = n2; g2.n = md.Kneed; g2.k = k23; g2.kidx = d_srccol + md.s + md.k1;
+        gd.push_back(g2);
+        gm = std::max(gm, std::max(md.n1, n2));
+        gn = std::max(gn, md.Kneed);
+      }
+      BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+      BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, gn));
+    }
+    if (max_ndef > 0) {
+      for (int b0 = 0; b0 < nm; b0 += 65535) {
+        const int nb = std::min(65535, nm - b0);
+        hipLaunchKernelGGL(dc_copy_deflated, dim3(max_ndef, nb), dim3(64), 0, st,
+                           (const MergeDesc*)(d_descs + b0), (const int*)d_defsrc,
+                           (const int*)d_defdst, (const double*)Qc, Qn, N);
+      }
+      BK_CHECK_LAUNCH();
+    }
+    // host vectors (gd, descs) must outlive the async copies
+    BK_HIP(hipStreamSynchronize(st));
+    std::swap(Qc, Qn);
+  }
+  if (n == 1) {
+    vals_desc.assign(1, dadj[0]);
+    src_cols.assign(1, 0);
+    nv_final = 1;
+  }
+  (void)nv_final;
+  *Qfinal = Qc;
+  return BIGKRLS_OK;
+}
+
+// =============================================================================
+// phase 3: back-transform
+// =============================================================================
+// Vp (ne x pw): reflectors of panel [j0, j0+pw) restricted to rows j0+1..n-1
+__global__ void bt_extract_panel(const double* __restrict__ W, int n, int j0, int pw,
+                                 double* __restrict__ Vp, int ne) {
+  const int64_t total = (int64_t)ne * pw;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e % ne), k = (int)(e / ne);
+    const int row = j0 + 1 + r, c = j0 + k;
+    double v = 0.0;
+    if (row == c + 1) v = 1.0;
+    else if (row > c + 1) v = W[row + (int64_t)c * n];
+    Vp[e] = v;
+  }
+}
+
+// T (pw x pw upper triangular) from G = Vp'Vp and tau (LAPACK dlarft, forward/columnwise)
+__global__ __launch_bounds__(64) void bt_build_t(const double* __restrict__ G, int pw,
+                                                 const double* __restrict__ tau,
+                                                 double* __restrict__ T) {
+  __shared__ double sT[TRD_NB * TRD_NB];
+  const int t = threadIdx.x;
+  for (int e = t; e < pw * pw; e += 64) sT[e] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < pw; ++i) {
+    const double ti = tau[i];
+    // T[0:i, i] = -tau_i * T[0:i,0:i] * G[0:i, i]
+    double acc = 0.0;
+    if (t < i) {
+      for (int k = t; k < i; ++k) acc += sT[t + k * pw] * G[k + i * pw];  // upper triangular rows
+      acc *= -ti;
+    }
+    __syncthreads();
+    if (t < i) sT[t + i * pw] = acc;
+    if (t == i) sT[i + i * pw] = ti;
+    __syncthreads();
+  }
+  for (int e = t; e < pw * pw; e += 64) T[e] = sT[e];
+}
+
+int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, double* Z,
+                   int64_t ldz, int nv) {
+  if (n < 3 || nv <= 0) return BIGKRLS_OK;
+  void* p = nullptr;
+  const int64_t need = (int64_t)n * TRD_NB + 3 * (int64_t)TRD_NB * TRD_NB + 2 * (int64_t)TRD_NB * nv;
+  BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p));
+  double* Vp = (double*)p;
+  double* G = Vp + (int64_t)n * TRD_NB;
+  double* T = G + TRD_NB * TRD_NB;
+  double* W1 = T + 2 * TRD_NB * TRD_NB;
+  double* W2 = W1 + (int64_t)TRD_NB * nv;
+  hipStream_t st = ctx->stream;
+  const int ncol = n - 2;  // reflectors c = 0..n-3 are non-trivial (c = n-2 has tau = 0)
+  const int npanel = (ncol + TRD_NB - 1) / TRD_NB;
+  for (int pb = npanel - 1; pb >= 0; --pb) {
+    const int j0 = pb * TRD_NB;
+    const int pw = std::min(TRD_NB, ncol - j0);
+    const int ne = n - j0 - 1;
+    int blocks = (int)std::min<int64_t>(((int64_t)ne * pw + 255) / 256, 4096);
+    hipLaunchKernelGGL(bt_extract_panel, dim3(blocks), dim3(256), 0, st, W, n, j0, pw, Vp, ne);
+    BK_CHECK_LAUNCH();
+    BK_TRY(gemm(ctx, 1, 0, pw, pw, ne, 1.0, Vp, ne, Vp, ne, 0.0, G, pw));
+    hipLaunchKernelGGL(bt_build_t, dim3(1), dim3(64), 0, st, (const double*)G, pw, tau + j0, T);
+    BK_CHECK_LAUNCH();
+    double* Zs = Z + (j0 + 1);
+    BK_TRY(gemm(ctx, 1, 0, pw, nv, ne, 1.0, Vp, ne, Zs, ldz, 0.0, W1, pw));
+    BK_TRY(gemm(ctx, 0, 0, pw, nv, pw, 1.0, T, pw, W1, pw, 0.0, W2, pw));
+    BK_TRY(gemm(ctx, 0, 0, ne, nv, pw, -1.0, Vp, ne, W2, pw, 1.0, Zs, ldz));
+  }
+  return BIGKRLS_OK;
+}
+
+}  // namespace
+
+int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
+          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs) {
+  BK_REQUIRE(A && vals && n64 > 0 && n64 < (1ll << 30), "eigen: bad matrix");
+  BK_REQUIRE(n_vals > 0 && n_vals <= n64, "eigen: n_vals out of range");
+  BK_REQUIRE(n_vecs_max >= 0 && n_vecs_max <= n64, "eigen: n_vecs_max out of range");
+  BK_REQUIRE(n_vecs_max == 0 || (vecs && ldv >= n64), "eigen: bad eigenvector buffer");
+  const int n = (int)n64;
+  const int64_t N = n;
+  hipStream_t st = ctx->stream;
+  void *pW = nullptr, *pQ0 = nullptr, *pQ1 = nullptr, *pU = nullptr, *pP = nullptr, *pV = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_EIG_A, N * N * sizeof(double), &pW));
+  BK_TRY(ws_get(ctx, SLOT_EIG_PANEL, 4 * N * TRD_NB * sizeof(double), &pP));
+  BK_TRY(ws_get(ctx, SLOT_EIG_VEC, (5 * N + 4 * TRD_NB + 2 * ((N + 255) / 256 + 2)) * sizeof(double), &pV));
+  double* W = (double*)pW;
+  double* P1 = (double*)pP;
+  double* P2 = P1 + 2 * N * TRD_NB;
+  double* d = (double*)pV;
+  double* e = d + N;
+  double* tau = e + N;
+  double* scratch = tau + N;
+  BK_TRY(copy_matrix(ctx, A, N, N, lda, W, N));
+  BK_HIP(hipMemsetAsync(d, 0, 3 * N * sizeof(double), st));
+  if (n >= 2) BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch));
+  else BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
+  std::vector<double> hd(n), he(n);
+  BK_HIP(hipMemcpyAsync(hd.data(), d, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  BK_HIP(hipMemcpyAsync(he.data(), e, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  BK_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(hd[i]) || (i < n - 1 && !std::isfinite(he[i]))) {
+      set_error("eigen: non-finite entries after tridiagonalisation (NaN/Inf in the input?)");
+      return BIGKRLS_EINVAL;
+    }
+  BK_TRY(ws_get(ctx, SLOT_EIG_Q0, N * N * sizeof(double), &pQ0));
+  BK_TRY(ws_get(ctx, SLOT_EIG_Q1, N * N * sizeof(double), &pQ1));
+  BK_TRY(ws_get(ctx, SLOT_EIG_U, N * N * sizeof(double), &pU));
+  std::vector<double> vals_desc;
+  std::vector<int> src_cols;
+  double* Qfin = nullptr;
+  BK_TRY(divide_conquer(ctx, n, hd, he, (double*)pQ0, (double*)pQ1, (double*)pU, n_vals,
+                        n_vecs_max, keep_thresh, vals_desc, src_cols, &Qfin));
+  BK_HIP(hipMemcpyAsync(vals, vals_desc.data(), n_vals * sizeof(double), hipMemcpyHostToDevice, st));
+  const int nv = (int)src_cols.size();
+  if (h_n_vecs) *h_n_vecs = nv;
+  if (nv > 0 && n_vecs_max > 0) {
+    void* pidx = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)10 * n * sizeof(int), &pidx));
+    int* d_src = (int*)pidx;
+    BK_HIP(hipMemcpyAsync(d_src, src_cols.data(), nv * sizeof(int), hipMemcpyHostToDevice, st));
+    int blocks = (int)std::min<int64_t>((N * nv + 255) / 256, 8192);
+    hipLaunchKernelGGL(gather_cols, dim3(blocks), dim3(256), 0, st, n, nv, (const int*)d_src,
+                       (const double*)Qfin, N, vecs, ldv);
+    BK_CHECK_LAUNCH();
+    BK_TRY(back_transform(ctx, W, n, tau, vecs, ldv, nv));
+  }
+  BK_HIP(hipStreamSynchronize(st));
+  return BIGKRLS_OK;
+}
+
+}  // namespace bk

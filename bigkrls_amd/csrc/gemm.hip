@@ -1,0 +1,439 @@
+// fp64 MFMA GEMM core for gfx950 (v_mfma_f64_16x16x4_f64) with pluggable epilogues.
+//
+// One core serves:
+//   * the Gaussian kernel build  K = exp(-(|a_i|^2 + |b_j|^2 - 2 a_i.b_j)/sigma)
+//     (replaces the scalar double loops of src/gauss_kernel.cpp:13-30 and
+//     src/temp_kernel.cpp:13-30)  -- "NT" product with a fused norm+exp epilogue;
+//   * the cross-products of src/crossprod.cpp:13-85 (A'B, A'A, AB', AA');
+//   * every GEMM inside the eigensolver, the variance matrices and the
+//     marginal-effects pass.
+//
+// Tiling (CDNA4, wave64): block tile 128 x BN x 16 with 256 threads = 4 waves in a
+// 2 x 2 grid; each wave owns 64 x BN/2 as 4 x (BN/32) MFMA tiles of 16 x 16.
+// Operands are staged global -> registers -> LDS (double buffered, one barrier per
+// k-tile); LDS tiles are k-major with a rotate+xor swizzle so that both the
+// fragment reads (ds_read_b64, 16 consecutive doubles per k row) and the
+// transposing stores are bank-conflict free.
+//
+// MFMA operand mapping (f64 16x16x4: lane l supplies A[i=l&15][k=l>>4] and
+// B[k=l>>4][j=l&15]; result reg r of lane l is D[i=(l>>4)+4r][j=l&15]):
+// we feed the N-side fragment as the MFMA "A" and the M-side fragment as the MFMA
+// "B", so that the lane index (l&15) runs along the column-major-contiguous M
+// dimension of C and every 16 lanes store one 128-byte segment.
+#include "common.h"
+
+namespace bk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+template <int W>
+__device__ __forceinline__ int lds_idx(int k, int x) {
+  return k * W + ((((x >> 4) ^ (k & (W / 16 - 1))) << 4) | ((x + k) & 15));
+}
+
+// Load a W x 16 operand tile into registers. Element (x, k) lives at
+// src[x*sx + k*sk]; CONTIG_X says which of the two strides is 1.
+template <bool CONTIG_X, int W>
+__device__ __forceinline__ void tile_load(const double* __restrict__ src, int64_t ld, int x0,
+                                          int k0, int xmax, int kmax, double (&r)[W / 16],
+                                          const int* __restrict__ kidx = nullptr) {
+  const int t = threadIdx.x;
+  if (CONTIG_X) {
+    const int x = t % W;
+    const int kb = t / W;
+    constexpr int KS = NT / W;
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q) {
+      const int k = kb + q * KS;
+      const int gx = x0 + x, gk = k0 + k;
+      double v = 0.0;
+      if (gx < xmax && gk < kmax) {
+        const int64_t col = kidx ? (int64_t)kidx[gk] : (int64_t)gk;
+        v = src[(int64_t)gx + col * ld];
+      }
+      r[q] = v;
+    }
+  } else {
+    const int k = t & 15;
+    const int xb = t >> 4;
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q) {
+      const int x = xb + 16 * q;
+      const int gx = x0 + x, gk = k0 + k;
+      r[q] = (gx < xmax && gk < kmax) ? src[(int64_t)gk + (int64_t)gx * ld] : 0.0;
+    }
+  }
+}
+
+template <bool CONTIG_X, int W>
+__device__ __forceinline__ void tile_store(double* __restrict__ lds, const double (&r)[W / 16]) {
+  const int t = threadIdx.x;
+  if (CONTIG_X) {
+    const int x = t % W;
+    const int kb = t / W;
+    constexpr int KS = NT / W;
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q) lds[lds_idx<W>(kb + q * KS, x)] = r[q];
+  } else {
+    const int k = t & 15;
+    const int xb = t >> 4;
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q) lds[lds_idx<W>(k, xb + 16 * q)] = r[q];
+  }
+}
+
+struct GemmOperands {
+  const double* A;
+  const double* B;
+  int64_t lda, ldb;
+  int M, N, K;
+  const int* kidx;  // optional gather of A's columns (NN only): op(A)(:,k) = A(:, kidx[k])
+};
+
+// Computes the accumulators of the (m0, n0) block tile over k in [kbeg, kend).
+// TA/TB: operand is used transposed (op(A) = A' with A stored K x M, etc.).
+template <bool TA, bool TB, int BN>
+__device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0, int kbeg,
+                                          int kend, double* __restrict__ smem,
+                                          d4 (&acc)[4][BN / 32]) {
+  constexpr int NJ = BN / 32;
+  // A tile: op(A)(m,k). not transposed: A[m + k lda] -> contiguous along m.
+  constexpr bool A_CONTIG = !TA;
+  // B tile: op(B)(k,n). transposed: B stored N x K, B[n + k ldb] -> contiguous along n.
+  constexpr bool B_CONTIG = TB;
+  double* As[2] = {smem, smem + BK * BM};
+  double* Bs[2] = {smem + 2 * BK * BM, smem + 2 * BK * BM + BK * BN};
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave & 1) * 64;
+  const int wn = (wave >> 1) * (BN / 2);
+  const int lm = lane & 15;
+  const int lk = lane >> 4;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  double ra[BM / 16];
+  double rb[BN / 16];
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+  if (ntiles <= 0) return;
+
+  tile_load<A_CONTIG, BM>(g.A, g.lda, m0, kbeg, g.M, kend, ra, g.kidx);
+  tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
+  tile_store<A_CONTIG, BM>(As[0], ra);
+  tile_store<B_CONTIG, BN>(Bs[0], rb);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) {
+      const int k0 = kbeg + (t + 1) * BK;
+      tile_load<A_CONTIG, BM>(g.A, g.lda, m0, k0, g.M, kend, ra, g.kidx);
+      tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, k0, g.N, kend, rb);
+    }
+    const double* as = As[cur];
+    const double* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[4], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = as[lds_idx<BM>(kk + lk, wm + i * 16 + lm)];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = bs[lds_idx<BN>(kk + lk, wn + j * 16 + lm)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) {
+      tile_store<A_CONTIG, BM>(As[cur ^ 1], ra);
+      tile_store<B_CONTIG, BN>(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+  }
+}
+
+// Visit every accumulator element owned by this lane: f(m, n, value).
+template <int BN, class F>
+__device__ __forceinline__ void acc_foreach(const d4 (&acc)[4][BN / 32], int m0, int n0, F f) {
+  constexpr int NJ = BN / 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave & 1) * 64;
+  const int wn = (wave >> 1) * (BN / 2);
+  const int lm = lane & 15;
+  const int lk = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + i * 16 + lm;
+        const int n = n0 + wn + j * 16 + lk + 4 * r;
+        f(m, n, acc[i][j][r]);
+      }
+}
+
+constexpr size_t smem_bytes(int bn) { return (size_t)(2 * BK * BM + 2 * BK * bn) * sizeof(double); }
+
+// XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give
+// each XCD a contiguous run of tiles (neighbouring tiles share operand panels in
+// that XCD's L2). Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int nx = 8;
+  const int q = nblocks / nx, rem = nblocks % nx;
+  const int x = bid % nx, i = bid / nx;
+  // blocks of xcd x: q + (x < rem) of them
+  const int start = x * q + (x < rem ? x : rem);
+  return start + i;
+}
+
+// ---------------------------------------------------------------------------
+// plain GEMM kernels
+// ---------------------------------------------------------------------------
+template <bool TA, bool TB, int BN>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmOperands g, double alpha, double beta,
+                                                  double* __restrict__ C, int64_t ldc,
+                                                  int tiles_m, int tiles_n, int k_chunk,
+                                                  double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int ntile = tiles_m * tiles_n;
+  const int tid = xcd_remap(blockIdx.x, ntile);
+  const int tm = tid % tiles_m, tn = tid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * k_chunk;
+  const int kend = min(g.K, kbeg + k_chunk);
+  d4 acc[4][BN / 32];
+  gemm_tile<TA, TB, BN>(g, m0, n0, kbeg, kend, smem, acc);
+  if (partial != nullptr) {
+    double* P = partial + (int64_t)z * g.M * g.N;
+    const int M = g.M, N = g.N;
+    acc_foreach<BN>(acc, m0, n0, [&](int m, int n, double v) {
+      if (m < M && n < N) P[(int64_t)m + (int64_t)n * M] = v;
+    });
+  } else {
+    const int M = g.M, N = g.N;
+    if (beta == 0.0) {
+      acc_foreach<BN>(acc, m0, n0, [&](int m, int n, double v) {
+        if (m < M && n < N) C[(int64_t)m + (int64_t)n * ldc] = alpha * v;
+      });
+    } else {
+      acc_foreach<BN>(acc, m0, n0, [&](int m, int n, double v) {
+        if (m < M && n < N) {
+          const int64_t o = (int64_t)m + (int64_t)n * ldc;
+          C[o] = alpha * v + beta * C[o];
+        }
+      });
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const double* __restrict__ partial, int splits, int M, int N,
+                                     double alpha, double beta, double* __restrict__ C,
+                                     int64_t ldc) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + e];
+    const int m = (int)(e % M), n = (int)(e / M);
+    const int64_t o = (int64_t)m + (int64_t)n * ldc;
+    C[o] = (beta == 0.0) ? alpha * s : alpha * s + beta * C[o];
+  }
+}
+
+template <bool TA, bool TB, int BN>
+static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, double beta,
+                       double* C, int64_t ldc) {
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int ntile = tiles_m * tiles_n;
+  // split-K when the tile grid cannot fill 256 CUs and K is long
+  int splits = 1;
+  if (ntile < 512 && g.K >= 1024) {
+    splits = (1024 + ntile - 1) / ntile;
+    const int maxs = g.K / 256;
+    if (splits > maxs) splits = maxs;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  int k_chunk = ((g.K + splits - 1) / splits + BK - 1) / BK * BK;
+  if (k_chunk < BK) k_chunk = BK;
+  splits = (g.K + k_chunk - 1) / k_chunk;
+  if (splits < 1) splits = 1;
+  double* partial = nullptr;
+  if (splits > 1) {
+    void* p = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_GEMM_SPLITK, (int64_t)splits * g.M * g.N * sizeof(double), &p));
+    partial = (double*)p;
+  }
+  auto kern = gemm_kernel<TA, TB, BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem_bytes(BN)));
+    attr_set = true;
+  }
+  dim3 grid(ntile, splits);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), smem_bytes(BN), ctx->stream, g, alpha, beta, C, ldc,
+                     tiles_m, tiles_n, k_chunk, partial);
+  BK_CHECK_LAUNCH();
+  if (splits > 1) {
+    const int64_t total = (int64_t)g.M * g.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, partial,
+                       splits, g.M, g.N, alpha, beta, C, ldc);
+    BK_CHECK_LAUNCH();
+  }
+  return BIGKRLS_OK;
+}
+
+template <int BN>
+static int dispatch_trans(bigkrls_ctx* ctx, int ta, int tb, const GemmOperands& g, double alpha,
+                          double beta, double* C, int64_t ldc) {
+  if (!ta && !tb) return launch_gemm<false, false, BN>(ctx, g, alpha, beta, C, ldc);
+  if (!ta && tb) return launch_gemm<false, true, BN>(ctx, g, alpha, beta, C, ldc);
+  if (ta && !tb) return launch_gemm<true, false, BN>(ctx, g, alpha, beta, C, ldc);
+  return launch_gemm<true, true, BN>(ctx, g, alpha, beta, C, ldc);
+}
+
+__global__ void scale_matrix_kernel(double* C, int64_t ldc, int M, int N, double beta) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = (e % M) + (e / M) * ldc;
+    C[o] = (beta == 0.0) ? 0.0 : beta * C[o];
+  }
+}
+
+int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha,
+         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+         int64_t ldc) {
+  BK_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gemm: negative dimension");
+  BK_REQUIRE(m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31), "gemm: dimension too large");
+  if (m == 0 || n == 0) return BIGKRLS_OK;
+  if (k == 0 || alpha == 0.0) {
+    if (beta == 1.0) return BIGKRLS_OK;
+    int blocks = (int)std::min<int64_t>((m * n + 255) / 256, 2048);
+    hipLaunchKernelGGL(scale_matrix_kernel, dim3(blocks), dim3(256), 0, ctx->stream, C, ldc,
+                       (int)m, (int)n, beta);
+    BK_CHECK_LAUNCH();
+    return BIGKRLS_OK;
+  }
+  BK_REQUIRE(A && B && C, "gemm: null pointer");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)n, (int)k, nullptr};
+  if (n <= 32) return dispatch_trans<32>(ctx, ta, tb, g, alpha, beta, C, ldc);
+  if (n <= 64) return dispatch_trans<64>(ctx, ta, tb, g, alpha, beta, C, ldc);
+  return dispatch_trans<128>(ctx, ta, tb, g, alpha, beta, C, ldc);
+}
+
+// ---------------------------------------------------------------------------
+// batched NN GEMM (divide & conquer merges): one descriptor per problem
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_batched_nn_kernel(const GemmDesc* __restrict__ descs,
+                                                             int tiles_m_max) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const GemmDesc d = descs[blockIdx.y];
+  const int tm = blockIdx.x % tiles_m_max, tn = blockIdx.x / tiles_m_max;
+  const int m0 = tm * BM, n0 = tn * 128;
+  if (m0 >= d.m || n0 >= d.n) return;
+  GemmOperands g{d.A, d.B, d.lda, d.ldb, d.m, d.n, d.k, d.kidx};
+  d4 acc[4][4];
+  gemm_tile<false, false, 128>(g, m0, n0, 0, d.k, smem, acc);
+  double* C = d.C;
+  const int64_t ldc = d.ldc;
+  const int M = d.m, N = d.n;
+  acc_foreach<128>(acc, m0, n0, [&](int m, int n, double v) {
+    if (m < M && n < N) C[(int64_t)m + (int64_t)n * ldc] = v;
+  });
+}
+
+int gemm_batched_nn(bigkrls_ctx* ctx, const GemmDesc* d_descs, int n_batch, int max_m, int max_n) {
+  if (n_batch <= 0 || max_m <= 0 || max_n <= 0) return BIGKRLS_OK;
+  const int tiles_m = (max_m + BM - 1) / BM, tiles_n = (max_n + 127) / 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BK_HIP(hipFuncSetAttribute((const void*)gemm_batched_nn_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    attr_set = true;
+  }
+  // grid.y is limited to 65535
+  for (int b0 = 0; b0 < n_batch; b0 += 65535) {
+    const int nb = std::min(65535, n_batch - b0);
+    hipLaunchKernelGGL(gemm_batched_nn_kernel, dim3(tiles_m * tiles_n, nb), dim3(NT),
+                       smem_bytes(128), ctx->stream, d_descs + b0, tiles_m);
+    BK_CHECK_LAUNCH();
+  }
+  return BIGKRLS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian kernel block: out[i,j] = exp(-(na_i + nb_j - 2 a_i.b_j)/sigma)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
+                                                          const double* __restrict__ na,
+                                                          const double* __restrict__ nb,
+                                                          double neg_inv_sigma,
+                                                          double* __restrict__ out, int64_t ldo,
+                                                          int tiles_m, int tiles_n,
+                                                          int64_t diag_shift) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int ntile = tiles_m * tiles_n;
+  const int tid = xcd_remap(blockIdx.x, ntile);
+  const int tm = tid % tiles_m, tn = tid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * 128;
+  d4 acc[4][4];
+  gemm_tile<false, true, 128>(g, m0, n0, 0, g.K, smem, acc);
+  const int M = g.M, N = g.N;
+  // per-lane norms: rows m = m0 + wm + i*16 + lm (4 values), cols n (16 values)
+  acc_foreach<128>(acc, m0, n0, [&](int m, int n, double v) {
+    if (m < M && n < N) {
+      double d2 = na[m] + nb[n] - 2.0 * v;
+      d2 = d2 > 0.0 ? d2 : 0.0;
+      double kv = exp(d2 * neg_inv_sigma);
+      if ((int64_t)m == (int64_t)n + diag_shift) kv = 1.0;
+      out[(int64_t)m + (int64_t)n * ldo] = kv;
+    }
+  });
+}
+
+int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
+                 int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
+                 int64_t diag_shift) {
+  BK_REQUIRE(u >= 0 && v >= 0 && p > 0, "kernel_block: bad dimensions");
+  BK_REQUIRE(u < (1ll << 31) && v < (1ll << 31) && p < (1ll << 31), "kernel_block: too large");
+  BK_REQUIRE(sigma > 0.0, "kernel_block: sigma must be > 0");
+  if (u == 0 || v == 0) return BIGKRLS_OK;
+  BK_REQUIRE(A && B && out, "kernel_block: null pointer");
+  void *pna = nullptr, *pnb = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_NORMS_A, u * sizeof(double), &pna));
+  BK_TRY(ws_get(ctx, SLOT_NORMS_B, v * sizeof(double), &pnb));
+  BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
+  BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
+  GemmOperands g{A, B, lda, ldb, (int)u, (int)v, (int)p, nullptr};
+  const int tiles_m = (int)((u + BM - 1) / BM), tiles_n = (int)((v + 127) / 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    BK_HIP(hipFuncSetAttribute((const void*)kernel_block_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel_block_kernel, dim3(tiles_m * tiles_n), dim3(NT), smem_bytes(128),
+                     ctx->stream, g, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
+                     tiles_m, tiles_n, diag_shift);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
+}  // namespace bk

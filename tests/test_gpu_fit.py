@@ -1,0 +1,173 @@
+"""bigKRLS()/predict()/crossvalidate() on the GPU against the CPU oracle.
+
+Tolerance: north_star asks for 1e-6 relative fp64 on coefficients, fitted values,
+lambda and pointwise derivatives; written as TOL below."""
+import numpy as np
+import pytest
+
+from oracle import krls_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def assert_fit_parity(out, ref, tol=TOL, squares=True):
+    assert out["lastkeeper"] == ref["lastkeeper"]
+    assert rel(out["K.eigenvalues"], ref["K.eigenvalues"]) < 1e-11
+    assert abs(out["lambda"] - ref["lambda"]) <= tol * abs(ref["lambda"])
+    for k in ["coeffs", "yfitted", "derivatives", "avgderivatives", "var.avgderivatives",
+              "derivatives.std", "var.avgderivatives.std"]:
+        if k in ref:
+            assert rel(out[k], ref[k]) < tol, k
+    for k in ["R2", "R2AME", "Looe", "Neffective", "sigmasq"]:
+        if k in ref and ref[k] is not None:
+            assert abs(out[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-12), k
+    if squares:
+        for k in ["K", "vcov.est.c", "vcov.est.fitted"]:
+            o = out[k].to_numpy() if hasattr(out[k], "to_numpy") else out[k]
+            assert rel(o, ref[k]) < tol, k
+
+
+def test_fit_c1_config(ctx):
+    """BASELINE.json configs[0]: N=500 P=5 synthetic sin(X beta), full eigen, literal oracle."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(500, 5, 101)
+    tr_ref = orc.LambdaTrace(0, 0)
+    ref = orc.fit(y, X, literal=True, trace=tr_ref)
+    tr = []
+    out = bk.bigKRLS(y, X, ctx=ctx, trace=tr)
+    assert_fit_parity(out, ref)
+    # quirk Q8: identical golden-section branch sequence
+    assert len(tr) == len(tr_ref.probes)
+    for (l1, s1), (l2, s2) in zip(tr, tr_ref.probes):
+        assert abs(l1 - l2) <= 1e-12 * abs(l2) and abs(s1 - s2) <= 1e-8 * abs(s2)
+
+
+def test_fit_binary_column_truncated(ctx):
+    """Mirrors examples/numeric_convergence.md: N=500, P=6, one binary column, eigtrunc 0.01."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(500, 6, 2018, binary_last=True)
+    ref = orc.fit(y, X, eigtrunc=0.01, literal=True)
+    out = bk.bigKRLS(y, X, eigtrunc=0.01, ctx=ctx)
+    assert list(out["binaryindicator"]) == [False] * 5 + [True]
+    assert_fit_parity(out, ref)
+
+
+def test_fit_neig_partial(ctx):
+    import bigkrls_amd as bk
+    X, y = orc.synth(500, 5, 33)
+    ref = orc.fit(y, X, neig=50, literal=False)
+    out = bk.bigKRLS(y, X, Neig=50, ctx=ctx)
+    assert out["K.eigenvalues"].shape == (50,)
+    assert_fit_parity(out, ref)
+
+
+def test_fit_which_derivatives_q6(ctx):
+    """Quirk Q6: rescaling uses X.init.sd[1..P'] not the selected columns."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(300, 5, 44)
+    X[:, 1] *= 7.0
+    ref = orc.fit(y, X, which_derivatives=[2, 4], literal=True)
+    out = bk.bigKRLS(y, X, which_derivatives=[2, 4], ctx=ctx)
+    assert out["derivatives"].shape == (300, 2)
+    assert_fit_parity(out, ref)
+
+
+def test_fit_user_lambda_and_no_derivative(ctx):
+    import bigkrls_amd as bk
+    X, y = orc.synth(257, 3, 45)
+    ref = orc.fit(y, X, lam=0.3, derivative=False, literal=True)
+    out = bk.bigKRLS(y, X, lambda_=0.3, derivative=False, ctx=ctx)
+    assert out["lambda"] == 0.3
+    assert "derivatives" not in out
+    assert_fit_parity(out, ref)
+
+
+def test_fit_mtcars_reference_test(ctx):
+    """The reference's own test (tests/testthat/test_basic_usage.R:48-109): fit with
+    eigtrunc=0, predict with hp:=200, proportion 0.6875, Corolla kernel column."""
+    import csv, os
+    import bigkrls_amd as bk
+    here = os.path.dirname(__file__)
+    rows = list(csv.reader(open(os.path.join(here, "golden", "mtcars.csv"))))
+    names = [r[0] for r in rows[1:]]
+    M = np.array([[float(v) for v in r[1:]] for r in rows[1:]])
+    y, X = M[:, 0], M[:, 1:]
+    out = bk.bigKRLS(y, X, eigtrunc=0, ctx=ctx)
+    Xnew = X.copy()
+    Xnew[:, 2] = 200.0
+    fc = bk.predict(out, Xnew)
+    assert np.mean(fc["predicted"] < y) == 0.6875
+    gold = {r[0]: float(r[1]) for r in list(csv.reader(open(os.path.join(here, "golden", "mtcars_corolla_kernel.csv"))))[1:]}
+    s = np.asarray(out["K"])[:, names.index("Toyota Corolla")]
+    assert max(s[i] - gold[nm] for i, nm in enumerate(names)) < 0.01
+    ref = orc.fit(y, X, eigtrunc=0, literal=True)
+    assert_fit_parity(out, ref)
+
+
+def test_predict_with_se(ctx):
+    import bigkrls_amd as bk
+    X, y = orc.synth(400, 4, 46)
+    ref = orc.fit(y[:350], X[:350], literal=False)
+    out = bk.bigKRLS(y[:350], X[:350], ctx=ctx)
+    pr = orc.predict(ref, X[350:], se_pred=True)
+    po = bk.predict(out, X[350:], se_pred=True)
+    assert rel(po["predicted"], pr["predicted"]) < TOL
+    assert rel(po["se.pred"], pr["se.pred"]) < TOL
+    assert rel(po["newdataK"], pr["newdataK"]) < 1e-12
+    assert rel(po["vcov.est.pred"], pr["vcov.est.pred"]) < TOL
+
+
+def test_crossvalidate_explicit_indices(ctx):
+    import bigkrls_amd as bk
+    X, y = orc.synth(300, 3, 47)
+    rng = np.random.default_rng(0)
+    tr = np.sort(rng.choice(300, 240, replace=False))
+    te = np.setdiff1d(np.arange(300), tr)
+    ref = orc.crossvalidate_split(y, X, tr, te, literal=False)
+    out = bk.crossvalidate(y, X, seed=1, ptesting=20, train_idx=tr, ctx=ctx)
+    for k in ["pseudoR2_is", "pseudoR2_oos", "MSE_is", "MSE_oos", "pseudoR2AME_is",
+              "pseudoR2AME_oos", "MSE_AME_is", "MSE_AME_oos"]:
+        assert abs(out[k] - ref[k]) <= TOL * abs(ref[k]), k
+    folds = (np.arange(300) % 3) + 1
+    refk = orc.crossvalidate_kfolds(y, X, folds, literal=False)
+    outk = bk.crossvalidate(y, X, seed=1, Kfolds=3, folds=folds, ctx=ctx)
+    for k in ["R2_is", "R2_oos", "MSE_is", "MSE_oos", "R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos"]:
+        assert rel(outk[k], refk[k]) < TOL, k
+
+
+def test_validation_errors(ctx):
+    import bigkrls_amd as bk
+    X, y = orc.synth(50, 3, 1)
+    Xc = X.copy(); Xc[:, 1] = 2.0
+    with pytest.raises(ValueError, match="constant"):
+        bk.bigKRLS(y, Xc, ctx=ctx)
+    Xn = X.copy(); Xn[3, 0] = np.nan
+    with pytest.raises(ValueError, match="missing data"):
+        bk.bigKRLS(y, Xn, ctx=ctx)
+    with pytest.raises(ValueError, match="nrow"):
+        bk.bigKRLS(y[:-1], X, ctx=ctx)
+    with pytest.raises(ValueError, match="y is a constant"):
+        bk.bigKRLS(np.ones(50), X, ctx=ctx)
+    with pytest.raises(ValueError, match="eigtrunc"):
+        bk.bigKRLS(y, X, eigtrunc=2, ctx=ctx)
+    with pytest.raises(ValueError, match="vcov.est is needed"):
+        bk.bigKRLS(y, X, vcov_est=False, ctx=ctx)
+    with pytest.raises(ValueError, match="which.derivative"):
+        bk.bigKRLS(y, X, derivative=False, which_derivatives=[1], ctx=ctx)
+
+
+def test_fit_medium_n2000(ctx):
+    """Bigger than one tile grid / several reflector panels; default eigtrunc path off (n<=3000)."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(2000, 10, 102)
+    ref = orc.fit(y, X, literal=False)
+    T = {}
+    out = bk.bigKRLS(y, X, ctx=ctx, timings=T)
+    print("timings N=2000:", {k: round(v, 4) for k, v in T.items()})
+    assert_fit_parity(out, ref)
