@@ -97,6 +97,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C bigkrls_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as the system one). If this
+    # library pulled in the system runtime first, a later `import torch` would load a second
+    # HIP runtime into the process and neither would see the other's streams or memory.
+    # Importing torch first makes the dynamic loader bind us to the runtime torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

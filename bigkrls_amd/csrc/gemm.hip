@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
       double d2 = na[m] + nb[n] - 2.0 * v;
       d2 = d2 > 0.0 ? d2 : 0.0;
       double kv = exp(d2 * neg_inv_sigma);
-      if ((int64_t)m == (int64_t)n + diag_shift) kv = 1.0;
+      if (diag_shift >= 0 && (int64_t)m == (int64_t)n + diag_shift) kv = 1.0;
       out[(int64_t)m + (int64_t)n * ldo] = kv;
     }
   });

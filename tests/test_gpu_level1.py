@@ -55,7 +55,8 @@ def test_gauss_kernel_mtcars_golden(lib):
     X = M[:, 1:]
     Xs = (X - X.mean(0)) / X.std(0, ddof=1)
     out = F(np.zeros((32, 32)))
-    check(lib, lib.bigkrls_gauss_kernel(P(F(Xs)), 32, 10, 10.0, P(out)))
+    Xf = F(Xs)                                  # keep the buffer alive across the call
+    check(lib, lib.bigkrls_gauss_kernel(P(Xf), 32, 10, 10.0, P(out)))
     gold = {r[0]: float(r[1]) for r in list(csv.reader(open(os.path.join(here, "golden", "mtcars_corolla_kernel.csv"))))[1:]}
     s = out[:, names.index("Toyota Corolla")]
     diff = np.array([s[i] - gold[nm] for i, nm in enumerate(names)])
@@ -69,7 +70,8 @@ def test_temp_kernel(lib, u, v, p):
     A = rng.standard_normal((u, p))
     B = rng.standard_normal((v, p))
     out = F(np.zeros((u, v)))
-    check(lib, lib.bigkrls_temp_kernel(P(F(A)), u, P(F(B)), v, p, 2.5, P(out)))
+    Af, Bf = F(A), F(B)
+    check(lib, lib.bigkrls_temp_kernel(P(Af), u, P(Bf), v, p, 2.5, P(out)))
     assert np.max(np.abs(out - orc.temp_kernel_literal(A, B, 2.5))) < 1e-13
 
 
@@ -130,7 +132,8 @@ def test_solveforc_matches_literal_row_loop(lib, n, p, trunc):
         le = C.c_double()
         c = np.zeros(n)
         vals = np.ascontiguousarray(eig.values)
-        check(lib, lib.bigkrls_solveforc(P(Q), n, k, P(vals), vals.size, P(np.ascontiguousarray(ys)),
+        yc = np.ascontiguousarray(ys)
+        check(lib, lib.bigkrls_solveforc(P(Q), n, k, P(vals), vals.size, P(yc),
                                          lam, C.byref(le), P(c)))
         assert relerr(c, c_ref) < 1e-9
         assert abs(le.value - le_ref) / le_ref < 1e-9
@@ -143,7 +146,8 @@ def test_eigen_full(lib, n, p):
     K = orc.gauss_kernel_literal(X, float(p))
     vals = np.zeros(n)
     vecs = F(np.zeros((n, n)))
-    check(lib, lib.bigkrls_eigen(P(F(K)), n, n, P(vals), P(vecs)))
+    Kf = F(K)
+    check(lib, lib.bigkrls_eigen(P(Kf), n, n, P(vals), P(vecs)))
     ref_vals, _ = orc.big_eigen_literal(K, n)
     scale = np.abs(ref_vals).max()
     assert np.max(np.abs(vals - ref_vals)) / scale < 1e-12
@@ -159,7 +163,8 @@ def test_eigen_partial(lib, n, p, neig):
     K = orc.gauss_kernel_literal(X, float(p))
     vals = np.zeros(neig)
     vecs = F(np.zeros((n, neig)))
-    check(lib, lib.bigkrls_eigen(P(F(K)), n, neig, P(vals), P(vecs)))
+    Kf = F(K)
+    check(lib, lib.bigkrls_eigen(P(Kf), n, neig, P(vals), P(vecs)))
     ref_vals = np.linalg.eigvalsh(K)[::-1][:neig]
     scale = ref_vals[0]
     assert np.max(np.abs(vals - ref_vals)) / scale < 1e-12
@@ -173,14 +178,16 @@ def test_eigen_diagonal_and_degenerate(lib):
     d = np.linspace(1, 2, n)
     vals = np.zeros(n)
     vecs = F(np.zeros((n, n)))
-    check(lib, lib.bigkrls_eigen(P(F(np.diag(d))), n, n, P(vals), P(vecs)))
+    Df = F(np.diag(d))
+    check(lib, lib.bigkrls_eigen(P(Df), n, n, P(vals), P(vecs)))
     assert np.allclose(vals, d[::-1], rtol=0, atol=1e-15)
     assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-13
     # rank-2 projector plus identity: eigenvalues {3,3,1,...,1}
     rng = np.random.default_rng(0)
     Qr, _ = np.linalg.qr(rng.standard_normal((n, 2)))
     A = np.eye(n) + 2 * Qr @ Qr.T
-    check(lib, lib.bigkrls_eigen(P(F(A)), n, n, P(vals), P(vecs)))
+    Af = F(A)
+    check(lib, lib.bigkrls_eigen(P(Af), n, n, P(vals), P(vecs)))
     assert np.allclose(vals[:2], 3, atol=1e-13) and np.allclose(vals[2:], 1, atol=1e-13)
     assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-12
     assert np.max(np.abs(A @ vecs - vecs * vals)) < 1e-12
@@ -199,8 +206,8 @@ def test_derivmat_matches_literal(lib, n, p, binary):
     D_ref, var_ref = orc.derivmat_literal(Xs, K, V, w["coeffs"], float(p))
     D = F(np.zeros((n, p)))
     var = np.zeros(p)
-    check(lib, lib.bigkrls_derivmat(P(F(Xs)), n, p, P(F(K)), P(F(V)), P(D), P(var),
-                                    P(np.ascontiguousarray(w["coeffs"])), float(p)))
+    Xf, Kf, Vf, cf = F(Xs), F(K), F(V), np.ascontiguousarray(w["coeffs"])
+    check(lib, lib.bigkrls_derivmat(P(Xf), n, p, P(Kf), P(Vf), P(D), P(var), P(cf), float(p)))
     assert relerr(D, D_ref) < 1e-10
     assert np.max(np.abs(var - var_ref) / np.abs(var_ref)) < 1e-8
 
