@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- the bigKRLS() fit on MI355X, BASELINE.json's metric and config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full bigKRLS() fit (kernel -> eigen -> lambda search -> coefficients ->
+variance matrices -> marginal effects) of configs[2]: N=20000, P=20, fp64,
+eigtrunc=0.001, synthetic G(N,P,seed=103) inputs already resident in HBM when the
+timed region starts (the N x P input is 3.2 MB; the PCIe-inclusive figure is in
+DESIGN.md).  Rank 0 prints ONE JSON line.  For N > 1 the same fit is row-block
+partitioned over the ranks (strong scaling): see bigkrls_amd/dist.py.
+
+`roofline` is for the dominant kernel of the fit (the Householder symv of the
+tridiagonalisation, HBM-bound), measured live with HIP events on the launch
+stream; `kernel_gemm` reports the Gaussian-kernel GEMM the metric also names.
+`cpu_baseline` times the oracle's literal restatement of the reference on the
+host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 64 cyc)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--p", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=103)
+    ap.add_argument("--cpu-n", type=int, default=2000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(p, n_cpu, seed):
+    """Literal CPU restatement (oracle, kind 'port') of the same fit on a bounded sample."""
+    import numpy as np
+    from oracle import krls_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    X, y = orc.synth(n_cpu, p, seed)
+    T = {}
+    t0 = time.perf_counter()
+    orc.fit(y, X, literal=True, timings=T, return_squares=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(dt, 3), "unit": "s per fit", "cores": int(threads), "kind": "port",
+        "sample": (f"full literal fit (reference loop structure: N^2K/2-per-probe solveforc, 4N^3 V_yhat, "
+                   f"4N^3-per-column derivatives; LAPACK dsyevd/BLAS via scipy OpenBLAS) at N={n_cpu}, "
+                   f"P={p}: 1/{(20000 // n_cpu) ** 3} of the N^3 work of the N=20000 workload; "
+                   f"hand loops single-threaded like the reference, BLAS threads={threads}"),
+        "phases_s": {k: round(v, 3) for k, v in T.items()},
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import bigkrls_amd as bk
+    from bigkrls_amd.synth import synth
+
+    ctx = bk.Context(local_rank if world > 1 else 0)
+    X, y = synth(args.n, args.p, args.seed)
+
+    if world > 1:
+        from bigkrls_amd import dist as bkdist
+
+        def one_fit(timings):
+            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=False)
+    else:
+        def one_fit(timings):
+            return bk.bigKRLS(y, X, ctx=ctx, timings=timings)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_fit({})
+        del out
+    ctx.set_profile(True)
+    phase_sum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T = {}
+        out = one_fit(T)
+        for k, v in T.items():
+            phase_sum[k] = phase_sum.get(k, 0.0) + v
+        lastkeeper, lam = out["lastkeeper"], out["lambda"]
+        del out
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    sec_per_fit = dt / args.steps
+
+    symv_ms, symv_bytes, symv_n = ctx.get_profile("symv")
+    kb_ms, kb_flops, kb_n = ctx.get_profile("kernel_block")
+    tu_ms, tu_flops, tu_n = ctx.get_profile("trailing_update")
+    ctx.set_profile(False)
+
+    if rank == 0:
+        n, p = args.n, args.p
+        phases = {k: round(v / args.steps, 4) for k, v in phase_sum.items()}
+        symv_gbs = (symv_bytes / 1e9) / (symv_ms / 1e3) if symv_ms > 0 else 0.0
+        res = {
+            "metric": "bigKRLS_fit_wall_clock_s (full fit, N=20000, P=20, fp64)" if (n, p) == (20000, 20)
+                      else f"bigKRLS_fit_wall_clock_s (full fit, N={n}, P={p}, fp64)",
+            "value": round(sec_per_fit, 4),
+            "unit": "s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(sec_per_fit * 1e3, 2),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C3: bigKRLS() full fit, N={n}, P={p}, fp64, Neig=N, eigtrunc=0.001, "
+                                   "all derivatives, vcov.est=TRUE; G(N,P,seed) = sin(X beta)+0.25 eps",
+                       "n": n, "p": p, "seed": args.seed, "lastkeeper": int(lastkeeper),
+                       "lambda": float(lam),
+                       "parallelism": "1 GPU" if world == 1 else f"row-block x{world}, RCCL all-gather"},
+            "phases_s": phases,
+            "kernel_gemm": {
+                "tflops": round(kb_flops / (kb_ms / 1e3) / 1e12, 3) if kb_ms > 0 else None,
+                "frac_of_fp64_mfma_peak": round(kb_flops / (kb_ms / 1e3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if kb_ms > 0 else None,
+                "hbm_write_gbs": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3), 1) if kb_ms > 0 else None,
+                "ms": round(kb_ms / max(kb_n, 1), 4), "launches": kb_n,
+                "note": "2*N^2*P flops / launch; at P=20 the build is HBM-write bound (8 N^2 bytes)"},
+            "trailing_update": {
+                "tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3) if tu_ms > 0 else None,
+                "launches": tu_n},
+            "roofline": {
+                "kernel": "trd_k2 (Householder symv over the trailing matrix, one launch per column)",
+                "bound": "hbm",
+                "achieved": round(symv_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(symv_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "launches_sampled": symv_n,
+                "avg_launch_us": round(symv_ms * 1e3 / max(symv_n, 1), 2),
+                "note": "achieved = 8*L^2 algorithmic bytes per launch (L = trailing size) / HIP-event duration, "
+                        "summed over the sampled launches (every 8th column)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p, args.cpu_n, args.seed)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

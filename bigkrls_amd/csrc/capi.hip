@@ -57,6 +57,50 @@ int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out) {
   return BIGKRLS_OK;
 }
 
+static bigkrls_ctx::ProfEntry* prof_entry(bigkrls_ctx* ctx, const char* name) {
+  for (auto& e : ctx->prof)
+    if (e.name == name) return &e;
+  ctx->prof.emplace_back();
+  ctx->prof.back().name = name;
+  return &ctx->prof.back();
+}
+
+int prof_begin(bigkrls_ctx* ctx, const char* name, double work) {
+  if (!ctx->profile) return BIGKRLS_OK;
+  bigkrls_ctx::ProfSample s{};
+  BK_HIP(hipEventCreate(&s.e0));
+  BK_HIP(hipEventCreate(&s.e1));
+  s.work = work;
+  BK_HIP(hipEventRecord(s.e0, ctx->stream));
+  prof_entry(ctx, name)->pending.push_back(s);
+  return BIGKRLS_OK;
+}
+
+int prof_end(bigkrls_ctx* ctx, const char* name) {
+  if (!ctx->profile) return BIGKRLS_OK;
+  auto* e = prof_entry(ctx, name);
+  if (e->pending.empty()) return BIGKRLS_OK;
+  BK_HIP(hipEventRecord(e->pending.back().e1, ctx->stream));
+  return BIGKRLS_OK;
+}
+
+static int prof_flush(bigkrls_ctx* ctx) {
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& e : ctx->prof) {
+    for (auto& s : e.pending) {
+      float ms = 0.f;
+      BK_HIP(hipEventElapsedTime(&ms, s.e0, s.e1));
+      e.ms += ms;
+      e.work += s.work;
+      e.launches += 1;
+      (void)hipEventDestroy(s.e0);
+      (void)hipEventDestroy(s.e1);
+    }
+    e.pending.clear();
+  }
+  return BIGKRLS_OK;
+}
+
 static int check_ctx(bigkrls_ctx* ctx) {
   if (!ctx) {
     set_error("null context");
@@ -194,6 +238,25 @@ int bigkrls_ctx_sync(bigkrls_ctx* ctx) {
 }
 
 void* bigkrls_ctx_stream(bigkrls_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int bigkrls_ctx_set_profile(bigkrls_ctx* ctx, int enable) {
+  BK_TRY(check_ctx(ctx));
+  BK_TRY(prof_flush(ctx));
+  ctx->profile = enable != 0;
+  if (enable) ctx->prof.clear();
+  return BIGKRLS_OK;
+}
+
+int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms, double* total_work,
+                            int64_t* launches) {
+  BK_TRY(check_ctx(ctx));
+  BK_REQUIRE(name && total_ms && total_work && launches, "get_profile: null argument");
+  BK_TRY(prof_flush(ctx));
+  *total_ms = 0; *total_work = 0; *launches = 0;
+  for (auto& e : ctx->prof)
+    if (e.name == name) { *total_ms = e.ms; *total_work = e.work; *launches = e.launches; }
+  return BIGKRLS_OK;
+}
 
 int64_t bigkrls_ctx_workspace_bytes(bigkrls_ctx* ctx) {
   if (!ctx) return 0;

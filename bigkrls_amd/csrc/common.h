@@ -52,6 +52,11 @@ struct bigkrls_ctx {
   // pinned host scratch for small scalar read-backs
   double* h_pinned = nullptr;
   int64_t h_pinned_doubles = 0;
+  // optional HIP-event sampling of named kernels (bench.py roofline numbers)
+  bool profile = false;
+  struct ProfSample { hipEvent_t e0, e1; double work; };
+  struct ProfEntry { std::string name; std::vector<ProfSample> pending; double ms = 0, work = 0; int64_t launches = 0; };
+  std::vector<ProfEntry> prof;
 };
 
 namespace bk {
@@ -82,6 +87,10 @@ enum Slot {
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
+// Bracket one launch with HIP events when ctx->profile is on: call prof_begin before the
+// launch and prof_end after it; `work` is the launch's algorithmic bytes (or flops).
+int prof_begin(bigkrls_ctx* ctx, const char* name, double work);
+int prof_end(bigkrls_ctx* ctx, const char* name);
 int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out);
 
 // ---- gemm.hip -----------------------------------------------------------------

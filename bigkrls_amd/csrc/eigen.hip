@@ -253,8 +253,11 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
                          (const double*)part2, np2, (const double*)tau, d, part1);
       const int L = n - c - 1;
       const int nb2 = (L + 2 * i + 15) / 16;
+      const bool sample = ctx->profile && (c % 8 == 0);
+      if (sample) BK_TRY(prof_begin(ctx, "symv", 8.0 * (double)L * (double)L));
       hipLaunchKernelGGL(trd_k2, dim3(nb2), dim3(256), 0, st, (const double*)W, n, c, i, pw, P1, P2,
                          (const double*)part1, nb1, y, tvec, e, tau);
+      if (sample) BK_TRY(prof_end(ctx, "symv"));
       const int nb3 = (L + 255) / 256;
       hipLaunchKernelGGL(trd_k3, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
                          (const double*)y, (const double*)tvec, (const double*)tau, part2);
@@ -268,8 +271,10 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
                        (const double*)part2, np2, (const double*)tau);
     BK_CHECK_LAUNCH();
     const int64_t mt = n - j1;
+    BK_TRY(prof_begin(ctx, "trailing_update", 2.0 * (double)mt * (double)mt * 2.0 * pw));
     BK_TRY(gemm(ctx, 0, 1, mt, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, 1.0, W + j1 + (int64_t)j1 * N,
                 N));
+    BK_TRY(prof_end(ctx, "trailing_update"));
   }
   BK_HIP(hipMemcpyAsync(d + (n - 1), W + (int64_t)(n - 1) * N + (n - 1), sizeof(double),
                         hipMemcpyDeviceToDevice, st));

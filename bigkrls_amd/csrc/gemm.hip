@@ -429,10 +429,12 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
     attr_set = true;
   }
+  BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
   hipLaunchKernelGGL(kernel_block_kernel, dim3(tiles_m * tiles_n), dim3(NT), smem_bytes(128),
                      ctx->stream, g, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
                      tiles_m, tiles_n, diag_shift);
   BK_CHECK_LAUNCH();
+  BK_TRY(prof_end(ctx, "kernel_block"));
   return BIGKRLS_OK;
 }
 

@@ -53,6 +53,16 @@ class Context:
     def workspace_bytes(self) -> int:
         return int(_lib.load().bigkrls_ctx_workspace_bytes(self.handle))
 
+    def set_profile(self, enable: bool):
+        _lib.call("bigkrls_ctx_set_profile", self.handle, int(bool(enable)))
+
+    def get_profile(self, name: str):
+        """(total_ms, total_work, launches) of the HIP-event samples of kernel `name`."""
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.call("bigkrls_ctx_get_profile", self.handle, name.encode(), C.byref(ms), C.byref(work),
+                  C.byref(n))
+        return float(ms.value), float(work.value), int(n.value)
+
     # ---- allocation ---------------------------------------------------------
     def empty(self, nrow: int, ncol: int = 1) -> "DeviceMatrix":
         t = self.torch.empty((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)

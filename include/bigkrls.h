@@ -61,6 +61,14 @@ void* bigkrls_ctx_stream(bigkrls_ctx* ctx);
 int64_t bigkrls_ctx_workspace_bytes(bigkrls_ctx* ctx);
 int bigkrls_ctx_release_workspace(bigkrls_ctx* ctx);
 
+/* HIP-event sampling of the dominant kernels on the context's stream (used by
+ * bench.py for the roofline figures; off by default). Names: "kernel_block" (work =
+ * flops 2*u*v*p), "symv" (work = bytes of the lower triangle streamed), 
+ * "trailing_update" (work = flops). */
+int bigkrls_ctx_set_profile(bigkrls_ctx* ctx, int enable);
+int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms,
+                            double* total_work, int64_t* launches);
+
 /* ---- device buffers (replaces bigmemory::big.matrix storage; reference type
  *      BigMatrix / SharedMemoryBigMatrix, e.g. src/gauss_kernel.cpp:34-35) ------ */
 int bigkrls_dev_alloc(bigkrls_ctx* ctx, int64_t nbytes, void** dptr);

@@ -1,0 +1,144 @@
+"""Worker for tests/test_dist_gloo.py: runs bigKRLS_dist on CPU under gloo with a
+numpy test double for the local kernels, and checks every rank's outputs against the
+single-process oracle. (Test infrastructure: this file may import the oracle.)"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import krls_oracle as orc  # noqa: E402
+from bigkrls_amd import dist as bkdist  # noqa: E402
+
+
+class NumpyBackend:
+    """Same interface as bigkrls_amd.dist.HipBackend on CPU tensors ((ncol, nrow) layout)."""
+
+    def from_numpy(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[:, None]
+        return torch.from_numpy(np.ascontiguousarray(a.T))
+
+    def empty(self, nrow, ncol):
+        return torch.zeros((ncol, nrow), dtype=torch.float64)
+
+    def kernel_cols(self, X, sigma, c0, c1, out):
+        Xn = X.numpy().T
+        out.copy_(torch.from_numpy(orc.temp_kernel_literal(Xn[c0:c1], Xn, sigma)))
+        for c in range(c0, c1):
+            out[c - c0, c] = 1.0
+
+    def eigen(self, K, neig, eigtrunc):
+        eo = orc.b_eigen(K.numpy().T, neig, eigtrunc)
+        return eo.values, eo.lastkeeper, torch.from_numpy(np.ascontiguousarray(eo.vectors.T)), \
+            torch.from_numpy(eo.values.copy())[None, :]
+
+    def qty_rows(self, Q, r0, r1, y):
+        return torch.from_numpy((Q.numpy()[:, r0:r1] @ y.numpy().ravel()[r0:r1])[None, :].copy())
+
+    def solveforc_rows(self, Q, r0, r1, d, a, lam, want_c):
+        k = Q.shape[0]
+        w = 1.0 / (d.numpy().ravel()[:k] + lam)
+        Qr = Q.numpy()[:, r0:r1].T
+        c = Qr @ (w * a.numpy().ravel())
+        g = (Qr * Qr) @ w
+        return float(np.sum((c / g) ** 2)), (torch.from_numpy(c[None, :].copy()) if want_c else None)
+
+    def gemv_t(self, Kcols, x):
+        return torch.from_numpy((Kcols.numpy() @ x.numpy().ravel())[None, :].copy())
+
+    def vcov_cols(self, Q, wv, r0, r1):
+        Qn = Q.numpy().T
+        k = Qn.shape[1]
+        V = (Qn * np.asarray(wv)[:k]) @ Qn[r0:r1].T
+        return torch.from_numpy(np.ascontiguousarray(V.T))
+
+    def deriv_rows(self, Kcols, r0, X, isbin, c, sigma):
+        # evaluate the O(N^2) identities on the full problem and keep this block's rows
+        nb, n = Kcols.shape
+        raise_if = None
+        Kfull = self._Kfull
+        Xn = X.numpy().T
+        D, S = _deriv_full(Xn, Kfull, c.numpy().ravel(), sigma)
+        return torch.from_numpy(np.ascontiguousarray(D[r0:r0 + nb].T)), \
+            torch.from_numpy(np.ascontiguousarray(S[r0:r0 + nb].T))
+
+    def deriv_var(self, Q, wv, S, scale):
+        Qn = Q.numpy().T
+        k = Qn.shape[1]
+        T = Qn.T @ S.numpy().T
+        return np.asarray(scale) * np.sum(np.asarray(wv)[:k, None] * T * T, axis=0)
+
+    def sync(self):
+        pass
+
+
+def _deriv_full(X, K, c, sigma):
+    n, p = X.shape
+    one = np.ones(n)
+    K1, Kc = K @ one, K @ c
+    D = np.empty((n, p)); S = np.empty((n, p))
+    for j in range(p):
+        x = X[:, j]
+        if np.unique(x).size == 2:
+            z0, z1 = x.min(), x.max()
+            sd = 1.0 / (z1 - z0); phi = -((z1 - z0) ** 2) / sigma
+            E, Ei = np.exp(phi), np.exp(-phi)
+            b = (x == z1).astype(float); hi = b == 1
+            Kb, Kbc = K @ b, K @ (b * c)
+            S1 = np.where(hi, Kb, K1 - Kb); O1 = np.where(hi, K1 - Kb, Kb)
+            Sc = np.where(hi, Kbc, Kc - Kbc); Oc = np.where(hi, Kc - Kbc, Kbc)
+            D[:, j] = sd * np.where(hi, 1.0, -1.0) * ((1 - E) * Sc + (1 - Ei) * Oc)
+            S[:, j] = np.where(hi, S1 + Ei * O1, E * S1 + O1) - np.where(hi, E * S1 + O1, S1 + Ei * O1)
+        else:
+            D[:, j] = (-2.0 / sigma) * (x * Kc - K @ (x * c))
+            S[:, j] = x * K1 - K @ x
+    return D, S
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, p = int(sys.argv[1]), int(sys.argv[2])
+    binary = bool(int(sys.argv[3]))
+    X, y = orc.synth(n, p, 77, binary_last=binary)
+    be = NumpyBackend()
+    # the test double needs the full K for its derivative identities: capture it from the all-gather
+    orig_eigen = be.eigen
+    def eigen_capture(K, neig, eigtrunc):
+        be._Kfull = K.numpy().T.copy()
+        return orig_eigen(K, neig, eigtrunc)
+    be.eigen = eigen_capture
+    tr = []
+    out = bkdist.bigKRLS_dist(y, X, backend=be, trace=tr)
+    ref_tr = orc.LambdaTrace(0, 0)
+    ref = orc.fit(y, X, literal=False, trace=ref_tr)
+
+    def rel(a, b):
+        a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+    assert out["lastkeeper"] == ref["lastkeeper"]
+    assert len(tr) == len(ref_tr.probes)
+    assert abs(out["lambda"] - ref["lambda"]) <= 1e-10 * ref["lambda"]
+    for k in ["coeffs", "yfitted", "derivatives", "var.avgderivatives", "avgderivatives"]:
+        assert rel(out[k], ref[k]) < 1e-9, (rank, k, rel(out[k], ref[k]))
+    for k in ["R2", "R2AME", "Looe", "Neffective", "sigmasq"]:
+        assert abs(out[k] - ref[k]) <= 1e-9 * abs(ref[k]), (rank, k)
+    r0, r1 = out["rows"]
+    nb, parts = bkdist.partition(n, world)
+    assert (r0, r1) == parts[rank]
+    assert rel(out["K.cols"].numpy().T, ref["K"][:, r0:r1]) < 1e-12
+    assert rel(out["vcov.est.c.cols"].numpy().T, ref["vcov.est.c"][:, r0:r1]) < 1e-9
+    assert rel(out["vcov.est.fitted.cols"].numpy().T, ref["vcov.est.fitted"][:, r0:r1]) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} OK")
+
+
+if __name__ == "__main__":
+    main()

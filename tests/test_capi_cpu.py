@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every
+symbol include/bigkrls.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "bigkrls.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bigkrls_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_every_reference_entry_point():
+    names = header_functions()
+    # one Level-1 drop-in per .Call routine of src/RcppExports.cpp:147-160 (BigNeffective is out of scope)
+    for n in ["gauss_kernel", "temp_kernel", "eigen", "solveforc", "multdiag", "crossprod", "xtx",
+              "tcrossprod", "xxt", "derivmat"]:
+        assert f"bigkrls_{n}" in names
+
+
+def test_library_exports_every_declared_symbol():
+    from bigkrls_amd import _lib
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), f"{name} declared in include/bigkrls.h but not exported"
+    # and the ctypes table covers the header exactly
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_lambda_bounds_host_helper_matches_r_loops():
+    """bigkrls_lambda_bounds is host-only: the U/L loops of bLambdaSearch (:16-36)."""
+    from bigkrls_amd import ops
+    from oracle import krls_oracle as orc
+    rng = np.random.default_rng(0)
+    for n in (50, 400, 3000):
+        d = np.sort(rng.gamma(0.3, 2.0, size=n))[::-1] * n / 10
+        d[-3:] = [1e-9, 1e-12, -1e-15]
+        L, U = ops.lambda_bounds(d, n)
+        L0, U0 = orc.lambda_bounds(d, n)
+        assert (L, U) == (L0, U0)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from bigkrls_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    st = lib.bigkrls_ctx_create(0, C.byref(h))
+    assert st == _lib.ENODEVICE
+    assert b"no CPU fallback" in lib.bigkrls_last_error() or b"device" in lib.bigkrls_last_error()
+    X = np.asfortranarray(np.ones((4, 2)))
+    out = np.asfortranarray(np.zeros((4, 4)))
+    st = lib.bigkrls_gauss_kernel(C.c_void_p(X.ctypes.data), 4, 2, 1.0, C.c_void_p(out.ctypes.data))
+    assert st != 0 and not out.any()
+    import bigkrls_amd as bk
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bk.Context(0)
+    with pytest.raises((RuntimeError, _lib.BigKRLSError)):
+        bk.bigKRLS(np.arange(10.0), np.random.default_rng(0).standard_normal((10, 2)))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bigkrls_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "krls_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_partition_covers_rows_once():
+    from bigkrls_amd.dist import partition
+    for n in (1, 7, 8, 9, 20000, 50001):
+        for world in (1, 2, 3, 8):
+            nb, parts = partition(n, world)
+            assert parts[0][0] == 0 and parts[-1][1] == n and nb * world >= n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert all(b - a <= nb for a, b in parts)

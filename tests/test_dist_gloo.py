@@ -1,0 +1,30 @@
+"""The N > 1 path (row-block partition + collectives of bigkrls_amd/dist.py) on CPU:
+world_size 2 and 3 under gloo, local kernels replaced by a numpy test double."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,n,p,binary", [(2, 101, 3, 0), (2, 160, 4, 1), (3, 100, 3, 1)])
+def test_row_block_fit_matches_oracle(world, n, p, binary):
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "_dist_worker.py"), str(n), str(p), str(binary)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == world
