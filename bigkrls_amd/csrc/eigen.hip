@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <cstdlib>
+#include <string>
 
 namespace bk {
 namespace {
@@ -234,8 +236,276 @@ __global__ __launch_bounds__(256) void trd_fin(int n, int c, int i, int pw,
   }
 }
 
+// -----------------------------------------------------------------------------
+// Symmetric symv, tiled: y = A22 v reading ONLY the lower triangle of A22 (the
+// HBM-bound half of the tridiagonalisation: 8 L(L+1)/2 bytes per column instead of
+// 8 L^2). The trailing matrix is cut into strips of 32 columns and row segments of
+// RS rows; block (strip s, segment g) streams its tile once with 16-byte loads
+// (lane = 2 consecutive rows, a wave covers 128 rows per instruction, 16 column
+// loads in flight per lane) and produces
+//   row partials  Prow[s][R]  = sum_{col in strip s, col <= R} A[R,col] v[col]
+//   col partials  Pcol[g][col] = sum_{R in segment g, R > col} A[R,col] v[R]
+// (32 per-lane accumulators, folded across the wave by a halving butterfly).
+// A second small kernel sums the partials in a fixed order (deterministic, no
+// atomics) 32 strips at a time; trd_k3 finishes the sum.
+// -----------------------------------------------------------------------------
+constexpr int SV_CW = 32;
+constexpr int SV_B = 8;    // column loads in flight per lane and batch
+
+template <int VEC> struct RowVec;
+template <> struct RowVec<1> { double v[1]; };
+template <> struct alignas(16) RowVec<2> { double v[2]; };
+
+__device__ __forceinline__ void house_scalars(const double* __restrict__ part1, int np1, double alpha,
+                                              double& beta, double& t, double& sc) {
+  double ss = 0.0;
+  for (int q = 0; q < np1; ++q) ss += part1[q];
+  if (ss == 0.0) {
+    beta = alpha; t = 0.0; sc = 0.0;
+  } else {
+    beta = -copysign(hypot(alpha, sqrt(ss)), alpha);
+    t = (beta - alpha) / beta;
+    sc = 1.0 / (alpha - beta);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void trd_symv_tiles(
+    const double* __restrict__ W, int n, int c, int i, int pw, const double* __restrict__ P1,
+    const double* __restrict__ part1, int np1, int RS, int nstrips, double* __restrict__ Prow,
+    double* __restrict__ Pcol, double* __restrict__ tvec, double* __restrict__ e,
+    double* __restrict__ tau) {
+  __shared__ double s_scale;
+  __shared__ double s_vc[SV_CW];
+  __shared__ double s_col[4][SV_CW];
+  __shared__ double s_diag[SV_CW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t N = n;
+  const int t0 = c + 1;
+  const double* x = W + (int64_t)c * N;  // x[R], R >= t0
+  if (tid == 0) {
+    double beta, t, sc;
+    house_scalars(part1, np1, x[t0], beta, t, sc);
+    s_scale = sc;
+    if (blockIdx.x == 0 && blockIdx.y == 0) { e[c] = beta; tau[c] = t; }
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  auto vrow = [&](int R) -> double {
+    return (R < t0 || R >= n) ? 0.0 : ((R == t0) ? 1.0 : x[R] * scale);
+  };
+  if ((int)blockIdx.x >= nstrips) {
+    // panel dots t1 = Wm'v (q < i), t2 = V'v (i <= q < 2i), row-segmented like the tiles:
+    // block (column group, segment g) -> partial sums Ppan[g][q]; trd_k3t adds the segments.
+    const int q0 = (((int)blockIdx.x - nstrips) * 4 + wave) * 4;
+    const int total = 2 * i;
+    const int r0 = (t0 - (t0 % VEC)) + (int)blockIdx.y * RS;
+    if (r0 >= n || q0 >= total) return;
+    const int r1 = min(n, r0 + RS);
+    const double* ptr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = min(q0 + u, total - 1);
+      ptr[u] = (q < i) ? P1 + (int64_t)(pw + q) * N : P1 + (int64_t)(q - i) * N;
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int R = r0 + lane * VEC; R < r1; R += 64 * VEC) {
+      const int Rl = min(R, n - VEC);
+      double v[VEC];
+#pragma unroll
+      for (int w2 = 0; w2 < VEC; ++w2) v[w2] = vrow(R + w2);
+      RowVec<VEC> a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const RowVec<VEC>*>(ptr[u] + Rl);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w2 = 0; w2 < VEC; ++w2) acc[u] += a[u].v[w2] * v[w2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double sm = wsum(acc[u]);
+      if (lane == 0 && q0 + u < total) tvec[(int64_t)blockIdx.y * (2 * TRD_NB) + q0 + u] = sm;
+    }
+    return;
+  }
+  const int s = blockIdx.x, g = blockIdx.y;
+  const int j0 = t0 + SV_CW * s;
+  const int ncols = min(SV_CW, n - j0);
+  const int j0e = j0 - (j0 % VEC);
+  const int seg0 = j0e + g * RS;
+  if (seg0 >= n) return;
+  const int seg1 = min(n, seg0 + RS);
+  if (tid < SV_CW) s_vc[tid] = (tid < ncols) ? vrow(j0 + tid) : 0.0;
+  __syncthreads();
+  constexpr int CH = 64 * VEC;
+  double col[SV_CW];
+#pragma unroll
+  for (int k = 0; k < SV_CW; ++k) col[k] = 0.0;
+  if (tid < SV_CW) s_diag[tid] = 0.0;
+  const double* Abase = W + (int64_t)j0 * N;
+  for (int chunk = seg0 + wave * CH; chunk < seg1; chunk += 4 * CH) {
+    const int R = chunk + lane * VEC;
+    double v[VEC], racc[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) { v[u] = vrow(R + u); racc[u] = 0.0; }
+    const bool inr = R < n;
+    const int Rl = min(R, n - VEC);
+    if (chunk < j0 + SV_CW) {
+      // the chunk that holds the diagonal block (wave 0, segment 0 only): triangular masks,
+      // column sums reduced per column straight away (rare path, kept small)
+#pragma unroll 1
+      for (int cc = 0; cc < ncols; ++cc) {
+        RowVec<VEC> a;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) a.v[u] = 0.0;
+        if (inr) a = *reinterpret_cast<const RowVec<VEC>*>(Abase + (int64_t)cc * N + R);
+        const double vc = s_vc[cc];
+        const int ca = j0 + cc;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          const int Ru = R + u;
+          racc[u] += ((Ru >= ca) ? a.v[u] : 0.0) * vc;
+          t += ((Ru > ca) ? a.v[u] : 0.0) * v[u];
+        }
+        t = wsum(t);
+        if (lane == 0) s_diag[cc] += t;
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < SV_CW; b += SV_B) {
+        // unconditional loads: out-of-range rows/columns are clamped to valid addresses and
+        // neutralised through v[u] == 0 / s_vc[cc] == 0 (their outputs are never stored)
+        RowVec<VEC> a[SV_B];
+#pragma unroll
+        for (int k = 0; k < SV_B; ++k) {
+          const int cc = min(b + k, ncols - 1);
+          a[k] = *reinterpret_cast<const RowVec<VEC>*>(Abase + (int64_t)cc * N + Rl);
+        }
+#pragma unroll
+        for (int k = 0; k < SV_B; ++k) {
+          const int cc = b + k;
+          const double vc = s_vc[cc];
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) {
+            racc[u] += a[k].v[u] * vc;
+            col[cc] += a[k].v[u] * v[u];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < VEC; ++u)
+      if (R + u < n) Prow[(int64_t)s * N + R + u] = racc[u];
+  }
+  // fold the 32 per-lane column accumulators across the wave: after the five halving
+  // steps lane l holds the total of column l >> 1 (lanes 2k and 2k+1 both).
+#pragma unroll
+  for (int half = 16, off = 32; half >= 1; half >>= 1, off >>= 1) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double send = hi ? col[k] : col[k + half];
+      const double keep = hi ? col[k + half] : col[k];
+      col[k] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  const double tot = col[0] + __shfl_xor(col[0], 1, 64);
+  if ((lane & 1) == 0) s_col[wave][lane >> 1] = tot;
+  __syncthreads();
+  if (tid < ncols)
+    Pcol[(int64_t)g * N + j0 + tid] =
+        ((s_col[0][tid] + s_col[1][tid]) + (s_col[2][tid] + s_col[3][tid])) + s_diag[tid];
+}
+
+// first level of the partial sum (32 strips per group) + v stored into the panel
+__global__ __launch_bounds__(256) void trd_symv_reduce(
+    const double* __restrict__ W, int n, int c, int i, int pw, int RS, int vec,
+    const double* __restrict__ part1, int np1, const double* __restrict__ Prow,
+    const double* __restrict__ Pcol, double* __restrict__ Prow2, double* __restrict__ P1,
+    double* __restrict__ P2) {
+  __shared__ double s_scale;
+  const int64_t N = n;
+  const int t0 = c + 1;
+  const double* x = W + (int64_t)c * N;
+  if (threadIdx.x == 0) {
+    double beta, t, sc;
+    house_scalars(part1, np1, x[t0], beta, t, sc);
+    s_scale = sc;
+  }
+  __syncthreads();
+  const int R = t0 + blockIdx.x * 256 + threadIdx.x;
+  if (R >= n) return;
+  const int q = blockIdx.y;
+  const int strip = (R - t0) / SV_CW;
+  const int s_lo = 32 * q, s_hi = min(32 * q + 31, strip);
+  double sum = 0.0;
+  for (int s = s_lo; s <= s_hi; ++s) sum += Prow[(int64_t)s * N + R];
+  if (q == 0) {
+    const int j0 = t0 + SV_CW * strip;
+    const int j0e = j0 - (j0 % vec);
+    const int nseg = (n - j0e + RS - 1) / RS;
+    for (int g = 0; g < nseg; ++g) sum += Pcol[(int64_t)g * N + R];
+    const double v = (R == t0) ? 1.0 : x[R] * s_scale;
+    P1[R + (int64_t)i * N] = v;
+    P2[R + (int64_t)(pw + i) * N] = v;
+  }
+  Prow2[(int64_t)q * N + R] = sum;
+}
+
+// K3 for the tiled symv: y_R = sum_q Prow2[q][R]
+__global__ __launch_bounds__(256) void trd_k3t(double* __restrict__ W, int n, int c, int i, int pw,
+                                               double* __restrict__ P1, double* __restrict__ P2,
+                                               const double* __restrict__ Prow2,
+                                               const double* __restrict__ tvec, int npseg,
+                                               const double* __restrict__ tau,
+                                               double* __restrict__ part2) {
+  __shared__ double st1[TRD_NB], st2[TRD_NB], sh[4];
+  const int tid = threadIdx.x;
+  const int64_t N = n;
+  const int L = n - c - 1;
+  if (tid < i) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int g = 0; g < npseg; ++g) {
+      a1 += tvec[g * (2 * TRD_NB) + tid];
+      a2 += tvec[g * (2 * TRD_NB) + i + tid];
+    }
+    st1[tid] = a1;
+    st2[tid] = a2;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + tid;
+  double pv = 0.0;
+  if (r < L) {
+    const int64_t row = c + 1 + r;
+    const double v = P1[row + (int64_t)i * N];
+    const int nq = r / (SV_CW * 32) + 1;
+    double s = 0.0;
+    for (int q = 0; q < nq; ++q) s += Prow2[(int64_t)q * N + row];
+    for (int k = 0; k < i; ++k)
+      s -= P1[row + (int64_t)k * N] * st1[k] + P1[row + (int64_t)(pw + k) * N] * st2[k];
+    const double wt = tau[c] * s;
+    P1[row + (int64_t)(pw + i) * N] = wt;
+    P2[row + (int64_t)i * N] = wt;
+    W[row + (int64_t)c * N] = v;
+    pv = wt * v;
+  }
+  pv = bsum256(pv, sh);
+  if (tid == 0) part2[blockIdx.x] = pv;
+}
+
+struct SymvWs {
+  double* Prow;
+  double* Pcol;
+  double* Prow2;
+  double* Ppan;   // [segment][2*TRD_NB] partial panel dots
+};
+
 int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, double* tau,
-                   double* P1, double* P2, double* scratch /* y[n] + tvec[2nb] + part1 + part2 */) {
+                   double* P1, double* P2, double* scratch /* y[n] + tvec[2nb] + part1 + part2 */,
+                   const SymvWs& sw, bool tiled) {
   const int maxb = (n + 255) / 256 + 1;
   double* y = scratch;
   double* tvec = y + n;
@@ -243,6 +513,8 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
   double* part2 = part1 + maxb;
   hipStream_t st = ctx->stream;
   const int64_t N = n;
+  const int vec = (n % 2 == 0) ? 2 : 1;
+  const int CH = 64 * vec;
   for (int j0 = 0; j0 < n - 1; j0 += TRD_NB) {
     const int pw = std::min(TRD_NB, n - 1 - j0);
     int np2 = 0;
@@ -252,15 +524,42 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
       hipLaunchKernelGGL(trd_k1, dim3(nb1), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
                          (const double*)part2, np2, (const double*)tau, d, part1);
       const int L = n - c - 1;
-      const int nb2 = (L + 2 * i + 15) / 16;
-      const bool sample = ctx->profile && (c % 8 == 0);
-      if (sample) BK_TRY(prof_begin(ctx, "symv", 8.0 * (double)L * (double)L));
-      hipLaunchKernelGGL(trd_k2, dim3(nb2), dim3(256), 0, st, (const double*)W, n, c, i, pw, P1, P2,
-                         (const double*)part1, nb1, y, tvec, e, tau);
-      if (sample) BK_TRY(prof_end(ctx, "symv"));
       const int nb3 = (L + 255) / 256;
-      hipLaunchKernelGGL(trd_k3, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
-                         (const double*)y, (const double*)tvec, (const double*)tau, part2);
+      const bool sample = ctx->profile && (c % 8 == 0);
+      if (!tiled) {
+        const int nb2 = (L + 2 * i + 15) / 16;
+        if (sample) BK_TRY(prof_begin(ctx, "symv", 4.0 * (double)L * (double)(L + 1)));
+        hipLaunchKernelGGL(trd_k2, dim3(nb2), dim3(256), 0, st, (const double*)W, n, c, i, pw, P1, P2,
+                           (const double*)part1, nb1, y, tvec, e, tau);
+        if (sample) BK_TRY(prof_end(ctx, "symv"));
+        hipLaunchKernelGGL(trd_k3, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
+                           (const double*)y, (const double*)tvec, (const double*)tau, part2);
+      } else {
+        const int nstrips = (L + SV_CW - 1) / SV_CW;
+        int RS = ((L / 6 + 4 * CH - 1) / (4 * CH)) * (4 * CH);
+        RS = std::max(4 * CH, std::min(RS, 8192));
+        const int nsegmax = (L + 1 + RS - 1) / RS;
+        const int t0e = (c + 1) - ((c + 1) % vec);
+        const int npan = (2 * i + 15) / 16;
+        const int nq = (nstrips + 31) / 32;
+        if (sample) BK_TRY(prof_begin(ctx, "symv", 4.0 * (double)L * (double)(L + 1)));
+        if (vec == 2)
+          hipLaunchKernelGGL(trd_symv_tiles<2>, dim3(nstrips + npan, nsegmax), dim3(256), 0, st,
+                             (const double*)W, n, c, i, pw, (const double*)P1, (const double*)part1,
+                             nb1, RS, nstrips, sw.Prow, sw.Pcol, sw.Ppan, e, tau);
+        else
+          hipLaunchKernelGGL(trd_symv_tiles<1>, dim3(nstrips + npan, nsegmax), dim3(256), 0, st,
+                             (const double*)W, n, c, i, pw, (const double*)P1, (const double*)part1,
+                             nb1, RS, nstrips, sw.Prow, sw.Pcol, sw.Ppan, e, tau);
+        hipLaunchKernelGGL(trd_symv_reduce, dim3(nb3, nq), dim3(256), 0, st, (const double*)W, n, c, i,
+                           pw, RS, vec, (const double*)part1, nb1, (const double*)sw.Prow,
+                           (const double*)sw.Pcol, sw.Prow2, P1, P2);
+        if (sample) BK_TRY(prof_end(ctx, "symv"));
+        const int npseg = (n - (t0e) + RS - 1) / RS;
+        hipLaunchKernelGGL(trd_k3t, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
+                           (const double*)sw.Prow2, (const double*)sw.Ppan, npseg, (const double*)tau,
+                           part2);
+      }
       np2 = nb3;
     }
     BK_CHECK_LAUNCH();
@@ -930,7 +1229,15 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   double* scratch = tau + N;
   BK_TRY(copy_matrix(ctx, A, N, N, lda, W, N));
   BK_HIP(hipMemsetAsync(d, 0, 3 * N * sizeof(double), st));
-  if (n >= 2) BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch));
+  // tiled-symv partial buffers live in the (later) U slot of the divide & conquer
+  const int64_t sv_prow = (N / SV_CW + 2) * N, sv_pcol = 10 * N, sv_prow2 = (N / (SV_CW * 32) + 2) * N;
+  const int64_t u_doubles = std::max<int64_t>(N * N, sv_prow + sv_pcol + sv_prow2 + 16 * 2 * TRD_NB);
+  BK_TRY(ws_get(ctx, SLOT_EIG_U, u_doubles * sizeof(double), &pU));
+  SymvWs sw{(double*)pU, (double*)pU + sv_prow, (double*)pU + sv_prow + sv_pcol,
+            (double*)pU + sv_prow + sv_pcol + sv_prow2};
+  const char* symv_env = getenv("BIGKRLS_SYMV");
+  const bool tiled = !(symv_env && std::string(symv_env) == "full");
+  if (n >= 2) BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw, tiled));
   else BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
   std::vector<double> hd(n), he(n);
   BK_HIP(hipMemcpyAsync(hd.data(), d, N * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -943,7 +1250,6 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     }
   BK_TRY(ws_get(ctx, SLOT_EIG_Q0, N * N * sizeof(double), &pQ0));
   BK_TRY(ws_get(ctx, SLOT_EIG_Q1, N * N * sizeof(double), &pQ1));
-  BK_TRY(ws_get(ctx, SLOT_EIG_U, N * N * sizeof(double), &pU));
   std::vector<double> vals_desc;
   std::vector<int> src_cols;
   double* Qfin = nullptr;
