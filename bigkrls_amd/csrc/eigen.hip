@@ -571,8 +571,11 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
     BK_CHECK_LAUNCH();
     const int64_t mt = n - j1;
     BK_TRY(prof_begin(ctx, "trailing_update", 2.0 * (double)mt * (double)mt * 2.0 * pw));
-    BK_TRY(gemm(ctx, 0, 1, mt, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, 1.0, W + j1 + (int64_t)j1 * N,
-                N));
+    if (tiled)
+      BK_TRY(syrk_lower(ctx, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, W + j1 + (int64_t)j1 * N, N));
+    else
+      BK_TRY(gemm(ctx, 0, 1, mt, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, 1.0,
+                  W + j1 + (int64_t)j1 * N, N));
     BK_TRY(prof_end(ctx, "trailing_update"));
   }
   BK_HIP(hipMemcpyAsync(d + (n - 1), W + (int64_t)(n - 1) * N + (n - 1), sizeof(double),

@@ -140,8 +140,10 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
     }
     const double* as = As[cur];
     const double* bs = Bs[cur];
+    const int kvalid = kend - (kbeg + t * BK);  // k-steps past the end are all zero: skip them
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
+      if (kk >= kvalid) break;
       double af[4], bf[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = as[lds_idx<BM>(kk + lk, wm + i * 16 + lm)];
@@ -339,6 +341,54 @@ int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, doub
 }
 
 // ---------------------------------------------------------------------------
+// symmetric rank-k update of the lower triangle: C(lower) += alpha * A B'
+// (A, B are m x k; used by the tridiagonalisation's trailing update
+//  A22 -= [V W][W V]', whose consumers only ever read the lower triangle).
+// Only tiles with tile_row >= tile_col are launched.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void syrk_lower_kernel(GemmOperands g, double alpha,
+                                                        double* __restrict__ C, int64_t ldc,
+                                                        int tiles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // blockIdx.x enumerates the lower-triangular tiles column by column
+  const int t = blockIdx.x;
+  // tn = largest integer with tn*tiles - tn(tn-1)/2 <= t
+  int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t)) * 0.5);
+  while (tn > 0 && tn * tiles - tn * (tn - 1) / 2 > t) --tn;
+  while ((tn + 1) * tiles - (tn + 1) * tn / 2 <= t) ++tn;
+  const int tm = tn + (t - (tn * tiles - tn * (tn - 1) / 2));
+  const int m0 = tm * BM, n0 = tn * 128;
+  d4 acc[4][4];
+  gemm_tile<false, true, 128>(g, m0, n0, 0, g.K, smem, acc);
+  const int M = g.M;
+  acc_foreach<128>(acc, m0, n0, [&](int m, int n, double v) {
+    if (m < M && n < M) {
+      const int64_t o = (int64_t)m + (int64_t)n * ldc;
+      C[o] += alpha * v;
+    }
+  });
+}
+
+int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+               const double* B, int64_t ldb, double* C, int64_t ldc) {
+  if (m <= 0 || k <= 0) return BIGKRLS_OK;
+  BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_lower: dimension too large");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
+  const int tiles = (int)((m + BM - 1) / BM);
+  const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BK_HIP(hipFuncSetAttribute((const void*)syrk_lower_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(syrk_lower_kernel, dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
+                     alpha, C, ldc, tiles);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // batched NN GEMM (divide & conquer merges): one descriptor per problem
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void gemm_batched_nn_kernel(const GemmDesc* __restrict__ descs,
@@ -381,6 +431,7 @@ int gemm_batched_nn(bigkrls_ctx* ctx, const GemmDesc* d_descs, int n_batch, int 
 // ---------------------------------------------------------------------------
 // Gaussian kernel block: out[i,j] = exp(-(na_i + nb_j - 2 a_i.b_j)/sigma)
 // ---------------------------------------------------------------------------
+template <int BN>
 __global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
                                                           const double* __restrict__ na,
                                                           const double* __restrict__ nb,
@@ -392,12 +443,11 @@ __global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
   const int ntile = tiles_m * tiles_n;
   const int tid = xcd_remap(blockIdx.x, ntile);
   const int tm = tid % tiles_m, tn = tid / tiles_m;
-  const int m0 = tm * BM, n0 = tn * 128;
-  d4 acc[4][4];
-  gemm_tile<false, true, 128>(g, m0, n0, 0, g.K, smem, acc);
+  const int m0 = tm * BM, n0 = tn * BN;
+  d4 acc[4][BN / 32];
+  gemm_tile<false, true, BN>(g, m0, n0, 0, g.K, smem, acc);
   const int M = g.M, N = g.N;
-  // per-lane norms: rows m = m0 + wm + i*16 + lm (4 values), cols n (16 values)
-  acc_foreach<128>(acc, m0, n0, [&](int m, int n, double v) {
+  acc_foreach<BN>(acc, m0, n0, [&](int m, int n, double v) {
     if (m < M && n < N) {
       double d2 = na[m] + nb[n] - 2.0 * v;
       d2 = d2 > 0.0 ? d2 : 0.0;
@@ -422,15 +472,16 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
   BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
   GemmOperands g{A, B, lda, ldb, (int)u, (int)v, (int)p, nullptr};
-  const int tiles_m = (int)((u + BM - 1) / BM), tiles_n = (int)((v + 127) / 128);
+  constexpr int KBN = 64;
+  const int tiles_m = (int)((u + BM - 1) / BM), tiles_n = (int)((v + KBN - 1) / KBN);
   static bool attr_set = false;
   if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)kernel_block_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    BK_HIP(hipFuncSetAttribute((const void*)kernel_block_kernel<KBN>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(KBN)));
     attr_set = true;
   }
   BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
-  hipLaunchKernelGGL(kernel_block_kernel, dim3(tiles_m * tiles_n), dim3(NT), smem_bytes(128),
+  hipLaunchKernelGGL(kernel_block_kernel<KBN>, dim3(tiles_m * tiles_n), dim3(NT), smem_bytes(KBN),
                      ctx->stream, g, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
                      tiles_m, tiles_n, diag_shift);
   BK_CHECK_LAUNCH();
