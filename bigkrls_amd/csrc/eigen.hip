@@ -250,7 +250,13 @@ __global__ __launch_bounds__(256) void trd_fin(int n, int c, int i, int pw,
 // atomics) 32 strips at a time; trd_k3 finishes the sum.
 // -----------------------------------------------------------------------------
 constexpr int SV_CW = 32;
-constexpr int SV_B = 8;    // column loads in flight per lane and batch
+#ifndef BK_SV_B
+#define BK_SV_B 16
+#endif
+#ifndef BK_SV_OCC
+#define BK_SV_OCC 2
+#endif
+constexpr int SV_B = BK_SV_B;    // column loads in flight per lane and batch
 
 template <int VEC> struct RowVec;
 template <> struct RowVec<1> { double v[1]; };
@@ -270,7 +276,7 @@ __device__ __forceinline__ void house_scalars(const double* __restrict__ part1, 
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256, 2) void trd_symv_tiles(
+__global__ __launch_bounds__(256, BK_SV_OCC) void trd_symv_tiles(
     const double* __restrict__ W, int n, int c, int i, int pw, const double* __restrict__ P1,
     const double* __restrict__ part1, int np1, int RS, int nstrips, double* __restrict__ Prow,
     double* __restrict__ Pcol, double* __restrict__ tvec, double* __restrict__ e,
@@ -338,6 +344,15 @@ __global__ __launch_bounds__(256, 2) void trd_symv_tiles(
   const int seg1 = min(n, seg0 + RS);
   if (tid < SV_CW) s_vc[tid] = (tid < ncols) ? vrow(j0 + tid) : 0.0;
   __syncthreads();
+  // the 32 v[col] values are wave-uniform: keep them in SGPRs for the whole block
+  double vcs[SV_CW];
+#pragma unroll
+  for (int k = 0; k < SV_CW; ++k) {
+    const double t = s_vc[k];
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(t));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(t));
+    vcs[k] = __hiloint2double(hi, lo);
+  }
   constexpr int CH = 64 * VEC;
   double col[SV_CW];
 #pragma unroll
@@ -381,12 +396,12 @@ __global__ __launch_bounds__(256, 2) void trd_symv_tiles(
 #pragma unroll
         for (int k = 0; k < SV_B; ++k) {
           const int cc = min(b + k, ncols - 1);
-          a[k] = *reinterpret_cast<const RowVec<VEC>*>(Abase + (int64_t)cc * N + Rl);
+          a[k] = *reinterpret_cast<const RowVec<VEC>*>((Abase + (int64_t)cc * N) + (unsigned)Rl);
         }
 #pragma unroll
         for (int k = 0; k < SV_B; ++k) {
           const int cc = b + k;
-          const double vc = s_vc[cc];
+          const double vc = vcs[cc];
 #pragma unroll
           for (int u = 0; u < VEC; ++u) {
             racc[u] += a[k].v[u] * vc;

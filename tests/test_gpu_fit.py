@@ -171,3 +171,19 @@ def test_fit_medium_n2000(ctx):
     out = bk.bigKRLS(y, X, ctx=ctx, timings=T)
     print("timings N=2000:", {k: round(v, 4) for k, v in T.items()})
     assert_fit_parity(out, ref)
+
+
+def test_dist_path_world1_hip_backend(ctx):
+    """bigkrls_amd.dist with the HIP backend on one GPU (no process group): every
+    backend entry point of the row-block path against the single-GPU fit and the oracle."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import dist as bkdist
+    X, y = orc.synth(700, 5, 48, binary_last=True)
+    ref = orc.fit(y, X, literal=False)
+    out = bkdist.bigKRLS_dist(y, X, ctx=ctx)
+    assert out["rows"] == (0, 700)
+    assert_fit_parity(out, ref, squares=False)
+    sd2 = orc.r_sd(y) ** 2
+    assert rel(out["K.cols"].cpu().numpy().T, ref["K"]) < 1e-12
+    assert rel(out["vcov.est.c.cols"].cpu().numpy().T, ref["vcov.est.c"]) < TOL
+    assert rel(out["vcov.est.fitted.cols"].cpu().numpy().T, ref["vcov.est.fitted"]) < TOL
