@@ -42,6 +42,19 @@ def parse():
     return ap.parse_args()
 
 
+def symv_traffic(alg_bytes_total, launches):
+    """Average HBM bytes per symv launch: algorithmic bytes x the traffic/algorithmic ratio that
+    rocprofv3 PMC passes measured for this kernel pair (profiles/r01_symv_pmc.json)."""
+    path = os.path.join(ROOT, "profiles", "r01_symv_pmc.json")
+    if launches <= 0 or not os.path.exists(path):
+        return None
+    try:
+        ratio = float(json.load(open(path))["traffic_over_algorithmic"])
+    except Exception:
+        return None
+    return round(alg_bytes_total / launches * ratio, 0)
+
+
 def cpu_baseline(p, n_cpu, seed):
     """Literal CPU restatement (oracle, kind 'port') of the same fit on a bounded sample."""
     import numpy as np
@@ -167,17 +180,22 @@ def main():
                 "tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3) if tu_ms > 0 else None,
                 "launches": tu_n},
             "roofline": {
-                "kernel": "trd_k2 (Householder symv over the trailing matrix, one launch per column)",
+                "kernel": "trd_symv_tiles(+trd_symv_reduce): Householder symv over the lower triangle of the "
+                          "trailing matrix, one launch pair per column of the tridiagonalisation",
                 "bound": "hbm",
                 "achieved": round(symv_gbs, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(symv_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": symv_traffic(symv_bytes, symv_n),
                 "launches_sampled": symv_n,
                 "avg_launch_us": round(symv_ms * 1e3 / max(symv_n, 1), 2),
-                "note": "achieved = 8*L^2 algorithmic bytes per launch (L = trailing size) / HIP-event duration, "
-                        "summed over the sampled launches (every 8th column)"},
+                "avg_algorithmic_bytes_per_launch": round(symv_bytes / max(symv_n, 1), 0),
+                "note": "achieved = 8*L(L+1)/2 algorithmic bytes per launch (lower triangle, L = trailing size) "
+                        "/ HIP-event duration on the launch stream, summed over the sampled launches (every 8th "
+                        "column); traffic = avg HBM bytes per launch = algorithmic x the PMC ratio measured in "
+                        "profiles/r01_symv_pmc.json (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, "
+                        "separate passes)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, args.cpu_n, args.seed)

@@ -256,6 +256,9 @@ constexpr int SV_CW = 32;
 #ifndef BK_SV_OCC
 #define BK_SV_OCC 2
 #endif
+#ifndef BK_SV_NCH
+#define BK_SV_NCH 1
+#endif
 constexpr int SV_B = BK_SV_B;    // column loads in flight per lane and batch
 
 template <int VEC> struct RowVec;
@@ -359,61 +362,74 @@ __global__ __launch_bounds__(256, BK_SV_OCC) void trd_symv_tiles(
   for (int k = 0; k < SV_CW; ++k) col[k] = 0.0;
   if (tid < SV_CW) s_diag[tid] = 0.0;
   const double* Abase = W + (int64_t)j0 * N;
-  for (int chunk = seg0 + wave * CH; chunk < seg1; chunk += 4 * CH) {
-    const int R = chunk + lane * VEC;
-    double v[VEC], racc[VEC];
+  constexpr int NCH = BK_SV_NCH;  // consecutive 128-row chunks a wave reads per column visit
+  for (int chunk = seg0 + wave * NCH * CH; chunk < seg1; chunk += 4 * NCH * CH) {
+    int R[NCH], Rl[NCH];
+    double v[NCH][VEC], racc[NCH][VEC];
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) { v[u] = vrow(R + u); racc[u] = 0.0; }
-    const bool inr = R < n;
-    const int Rl = min(R, n - VEC);
+    for (int h = 0; h < NCH; ++h) {
+      R[h] = chunk + h * CH + lane * VEC;
+      Rl[h] = min(R[h], n - VEC);
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) { v[h][u] = vrow(R[h] + u); racc[h][u] = 0.0; }
+    }
     if (chunk < j0 + SV_CW) {
-      // the chunk that holds the diagonal block (wave 0, segment 0 only): triangular masks,
+      // the rows that hold the diagonal block (wave 0, segment 0 only): triangular masks,
       // column sums reduced per column straight away (rare path, kept small)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
 #pragma unroll 1
-      for (int cc = 0; cc < ncols; ++cc) {
-        RowVec<VEC> a;
+        for (int cc = 0; cc < ncols; ++cc) {
+          RowVec<VEC> a;
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) a.v[u] = 0.0;
-        if (inr) a = *reinterpret_cast<const RowVec<VEC>*>(Abase + (int64_t)cc * N + R);
-        const double vc = s_vc[cc];
-        const int ca = j0 + cc;
-        double t = 0.0;
+          for (int u = 0; u < VEC; ++u) a.v[u] = 0.0;
+          if (R[h] < n) a = *reinterpret_cast<const RowVec<VEC>*>(Abase + (int64_t)cc * N + R[h]);
+          const double vc = s_vc[cc];
+          const int ca = j0 + cc;
+          double t = 0.0;
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) {
-          const int Ru = R + u;
-          racc[u] += ((Ru >= ca) ? a.v[u] : 0.0) * vc;
-          t += ((Ru > ca) ? a.v[u] : 0.0) * v[u];
+          for (int u = 0; u < VEC; ++u) {
+            const int Ru = R[h] + u;
+            racc[h][u] += ((Ru >= ca) ? a.v[u] : 0.0) * vc;
+            t += ((Ru > ca) ? a.v[u] : 0.0) * v[h][u];
+          }
+          t = wsum(t);
+          if (lane == 0) s_diag[cc] += t;
         }
-        t = wsum(t);
-        if (lane == 0) s_diag[cc] += t;
       }
     } else {
 #pragma unroll
       for (int b = 0; b < SV_CW; b += SV_B) {
         // unconditional loads: out-of-range rows/columns are clamped to valid addresses and
         // neutralised through v[u] == 0 / s_vc[cc] == 0 (their outputs are never stored)
-        RowVec<VEC> a[SV_B];
+        RowVec<VEC> a[SV_B][NCH];
 #pragma unroll
         for (int k = 0; k < SV_B; ++k) {
           const int cc = min(b + k, ncols - 1);
-          a[k] = *reinterpret_cast<const RowVec<VEC>*>((Abase + (int64_t)cc * N) + (unsigned)Rl);
+#pragma unroll
+          for (int h = 0; h < NCH; ++h)
+            a[k][h] = *reinterpret_cast<const RowVec<VEC>*>((Abase + (int64_t)cc * N) + (unsigned)Rl[h]);
         }
 #pragma unroll
         for (int k = 0; k < SV_B; ++k) {
           const int cc = b + k;
           const double vc = vcs[cc];
 #pragma unroll
-          for (int u = 0; u < VEC; ++u) {
-            racc[u] += a[k].v[u] * vc;
-            col[cc] += a[k].v[u] * v[u];
-          }
+          for (int h = 0; h < NCH; ++h)
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+              racc[h][u] += a[k][h].v[u] * vc;
+              col[cc] += a[k][h].v[u] * v[h][u];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
-    for (int u = 0; u < VEC; ++u)
-      if (R + u < n) Prow[(int64_t)s * N + R + u] = racc[u];
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int u = 0; u < VEC; ++u)
+        if (R[h] + u < n) Prow[(int64_t)s * N + R[h] + u] = racc[h][u];
   }
   // fold the 32 per-lane column accumulators across the wave: after the five halving
   // steps lane l holds the total of column l >> 1 (lanes 2k and 2k+1 both).
@@ -551,8 +567,9 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
                            (const double*)y, (const double*)tvec, (const double*)tau, part2);
       } else {
         const int nstrips = (L + SV_CW - 1) / SV_CW;
-        int RS = ((L / 6 + 4 * CH - 1) / (4 * CH)) * (4 * CH);
-        RS = std::max(4 * CH, std::min(RS, 8192));
+        const int rsq = 4 * CH * BK_SV_NCH;  // segments are whole numbers of block iterations
+        int RS = ((L / 6 + rsq - 1) / rsq) * rsq;
+        RS = std::max(rsq, std::min(RS, 8192));
         const int nsegmax = (L + 1 + RS - 1) / RS;
         const int t0e = (c + 1) - ((c + 1) % vec);
         const int npan = (2 * i + 15) / 16;
@@ -585,7 +602,8 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
                        (const double*)part2, np2, (const double*)tau);
     BK_CHECK_LAUNCH();
     const int64_t mt = n - j1;
-    BK_TRY(prof_begin(ctx, "trailing_update", 2.0 * (double)mt * (double)mt * 2.0 * pw));
+    BK_TRY(prof_begin(ctx, "trailing_update",
+                      (tiled ? (double)mt * (double)(mt + 1) : 2.0 * (double)mt * (double)mt) * 2.0 * pw));
     if (tiled)
       BK_TRY(syrk_lower(ctx, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, W + j1 + (int64_t)j1 * N, N));
     else

@@ -431,6 +431,7 @@ int gemm_batched_nn(bigkrls_ctx* ctx, const GemmDesc* d_descs, int n_batch, int 
 // ---------------------------------------------------------------------------
 // Gaussian kernel block: out[i,j] = exp(-(na_i + nb_j - 2 a_i.b_j)/sigma)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double exp_nonpos(double x);
 template <int BN>
 __global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
                                                           const double* __restrict__ na,
@@ -451,11 +452,247 @@ __global__ __launch_bounds__(NT) void kernel_block_kernel(GemmOperands g,
     if (m < M && n < N) {
       double d2 = na[m] + nb[n] - 2.0 * v;
       d2 = d2 > 0.0 ? d2 : 0.0;
-      double kv = exp(d2 * neg_inv_sigma);
+      double kv = exp_nonpos(d2 * neg_inv_sigma);
       if (diag_shift >= 0 && (int64_t)m == (int64_t)n + diag_shift) kv = 1.0;
       out[(int64_t)m + (int64_t)n * ldo] = kv;
     }
   });
+}
+
+// exp(x) for x <= 0 (the only domain the Gaussian kernel needs), ~20 fp64 VALU ops:
+// n = rint(x log2 e), r = x - n ln2 (two-term Cody-Waite), degree-13 Taylor/Horner on
+// |r| <= ln2/2 (truncation 4e-18), scale by 2^n with v_ldexp_f64 (gradual underflow to 0).
+// The kernel build is VALU-bound on the epilogue (rocprofv3: SQ_ACTIVE_INST_VALU), and the
+// library exp() costs ~45 instructions per element.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -746.0);
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                   // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);                 // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);                // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);                // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);               // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);                 // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);                // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);                // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);                // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);               // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);               // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// Small-P variant (P <= 128: the fit's own regime, P = 5..50): the operands are a few
+// MB and live in L2, the output is 8 N^2 bytes, so the kernel is HBM-write bound and the
+// only job is to keep many independent store streams in flight. No LDS, no barriers:
+// every wave owns one 32 x 32 output tile (2 x 2 MFMA tiles), pulls its fragments
+// straight from global/L2 in MFMA operand layout (16 consecutive rows = one 128-byte
+// segment per k), runs ceil(P/4) MFMA steps and the exp epilogue, and streams 128-byte
+// store segments. ~100 VGPRs -> 4-5 waves per SIMD cover the store latency.
+template <int KS>
+__global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
+    const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V,
+    int P, const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma,
+    double* __restrict__ out, int64_t ldo, int64_t diag_shift, int tiles_m, int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= ntiles) return;
+  const int tm = (int)(w % tiles_m), tn = (int)(w / tiles_m);
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int ma0 = min(m0 + lm, U - 1), ma1 = min(m0 + 16 + lm, U - 1);
+  const int nb0 = min(n0 + lm, V - 1), nb1 = min(n0 + 16 + lm, V - 1);
+  const double* a0p = A + ma0;
+  const double* a1p = A + ma1;
+  const double* b0p = B + nb0;
+  const double* b1p = B + nb1;
+  // norms of this lane's output columns / rows: issued first so that their latency hides
+  // behind the fragment loads
+  double nbv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nbv[j][r] = nb[min(n0 + j * 16 + lk + 4 * r, V - 1)];
+  double nam[2];
+  nam[0] = na[ma0];
+  nam[1] = na[ma1];
+  // K in chunks of KS MFMA steps (4 k each): all 4*KS fragment loads of a chunk are in
+  // flight before the first MFMA; k >= P reads a clamped address and is zeroed.
+  for (int kc0 = 0; kc0 < P; kc0 += 4 * KS) {
+    double fa0[KS], fa1[KS], fb0[KS], fb1[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = kc0 + 4 * s + lk;
+      const int64_t kc = min(k, P - 1);
+      fa0[s] = a0p[kc * lda];
+      fa1[s] = a1p[kc * lda];
+      fb0[s] = b0p[kc * ldb];
+      fb1[s] = b1p[kc * ldb];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bool kv = (kc0 + 4 * s + lk) < P;
+      const double a0 = kv ? fa0[s] : 0.0, a1 = kv ? fa1[s] : 0.0;
+      const double b0 = kv ? fb0[s] : 0.0, b1 = kv ? fb1[s] : 0.0;
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // 16-byte stores: adjacent lanes (rows 2t, 2t+1) swap one value so that the even lane
+  // owns rows (2t, 2t+1) of column n(r) and the odd lane the same rows of column n(r+1).
+  const bool odd = (lane & 1) != 0;
+  const bool vec_ok = ((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  // wave-uniform: does this 32 x 32 tile touch the forced-unit diagonal m == n + diag_shift ?
+  const bool has_diag = diag_shift >= 0 && (int64_t)m0 < (int64_t)n0 + 32 + diag_shift &&
+                        (int64_t)m0 + 32 > (int64_t)n0 + diag_shift;
+  const int dsh = (int)diag_shift;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int rp = 0; rp < 4; rp += 2) {
+      double kv[2][2];  // [i][r - rp]
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int n = n0 + j * 16 + lk + 4 * (rp + rr);
+        const double nbn = nbv[j][rp + rr];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int m = m0 + i * 16 + lm;
+          double d2 = fma(-2.0, acc[i][j][rp + rr], nam[i] + nbn);
+          d2 = fmax(d2, 0.0);
+          double e = exp_nonpos(d2 * neg_inv_sigma);
+          if (has_diag && (m - n) == dsh) e = 1.0;
+          kv[i][rr] = e;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + lm;
+        if (vec_ok) {
+          const double send = odd ? kv[i][0] : kv[i][1];
+          const double recv = __shfl_xor(send, 1, 64);
+          const double lo = odd ? recv : kv[i][0];
+          const double hi = odd ? kv[i][1] : recv;
+          const int mrow = m & ~1;                              // first of the row pair
+          const int n = n0 + j * 16 + lk + 4 * (rp + (odd ? 1 : 0));
+          if (n < V) {
+            double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
+            if (mrow + 1 < U) {
+              *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
+            } else if (mrow < U) {
+              dst[0] = lo;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int n = n0 + j * 16 + lk + 4 * (rp + rr);
+            if (m < U && n < V) out[(int64_t)m + (int64_t)n * ldo] = kv[i][rr];
+          }
+        }
+      }
+    }
+}
+
+// Tall variant of the same idea: a wave owns 64 rows x 16 columns (4 x 1 MFMA tiles), the
+// four waves of a block are stacked along the rows (256 x 16), and the XCD-aware block
+// order keeps vertically adjacent blocks on the same XCD. Every column of the output is
+// then written in 512-byte (wave) / 2-KB (block) contiguous runs -- HBM pages see long
+// bursts instead of isolated 128-byte lines.
+template <int KS>
+__global__ __launch_bounds__(NT) void kernel_block_tall_kernel(
+    const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V,
+    int P, const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma,
+    double* __restrict__ out, int64_t ldo, int64_t diag_shift, int blocks_m, int nblocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bid = xcd_remap(blockIdx.x, nblocks);
+  const int bm = bid % blocks_m, bn = bid / blocks_m;
+  const int m0 = bm * 256 + wave * 64, n0 = bn * 16;
+  if (m0 >= U) return;
+  const int lm = lane & 15, lk = lane >> 4;
+  d4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* ap[4];
+  double nam[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mi = min(m0 + 16 * i + lm, U - 1);
+    ap[i] = A + mi;
+    nam[i] = na[mi];
+  }
+  const double* bp = B + min(n0 + lm, V - 1);
+  double nbv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) nbv[r] = nb[min(n0 + lk + 4 * r, V - 1)];
+  for (int kc0 = 0; kc0 < P; kc0 += 4 * KS) {
+    double fa[4][KS], fb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int64_t kc = min(kc0 + 4 * s + lk, P - 1);
+      fb[s] = bp[kc * ldb];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i][s] = ap[i][kc * lda];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bool kv = (kc0 + 4 * s + lk) < P;
+      const double b = kv ? fb[s] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, kv ? fa[i][s] : 0.0, acc[i], 0, 0, 0);
+    }
+  }
+  const bool odd = (lane & 1) != 0;
+  const bool vec_ok = ((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int rp = 0; rp < 4; rp += 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + i * 16 + lm;
+      double kv[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int n = n0 + lk + 4 * (rp + rr);
+        double d2 = nam[i] + nbv[rp + rr] - 2.0 * acc[i][rp + rr];
+        d2 = d2 > 0.0 ? d2 : 0.0;
+        double e = exp_nonpos(d2 * neg_inv_sigma);
+        if (diag_shift >= 0 && (int64_t)m == (int64_t)n + diag_shift) e = 1.0;
+        kv[rr] = e;
+      }
+      if (vec_ok) {
+        const double send = odd ? kv[0] : kv[1];
+        const double recv = __shfl_xor(send, 1, 64);
+        const double lo = odd ? recv : kv[0];
+        const double hi = odd ? kv[1] : recv;
+        const int mrow = m & ~1;
+        const int n = n0 + lk + 4 * (rp + (odd ? 1 : 0));
+        if (n < V) {
+          double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
+          if (mrow + 1 < U) *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
+          else if (mrow < U) dst[0] = lo;
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int n = n0 + lk + 4 * (rp + rr);
+          if (m < U && n < V) out[(int64_t)m + (int64_t)n * ldo] = kv[rr];
+        }
+      }
+    }
+  }
 }
 
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
@@ -471,6 +708,38 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   BK_TRY(ws_get(ctx, SLOT_NORMS_B, v * sizeof(double), &pnb));
   BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
   BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
+  if (p <= 128) {
+    const int tiles_m = (int)((u + 31) / 32), tiles_n = (int)((v + 31) / 32);
+    const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+    BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
+    const int steps = (int)((p + 3) / 4);
+    const int chunks = (steps + 7) / 8;
+    const int ks = (steps + chunks - 1) / chunks;  // 1..8 MFMA steps per chunk, minimal padding
+    (void)ntiles;
+    const int blocks_m = (int)((u + 255) / 256), blocks_n = (int)((v + 15) / 16);
+    const int64_t nblk = (int64_t)blocks_m * blocks_n;
+    BK_REQUIRE(nblk < (1ll << 31), "kernel_block: too many tiles");
+    (void)nblk; (void)blocks_m;
+    const dim3 grid((unsigned)((ntiles + 3) / 4));
+#define BK_KBW(KS)                                                                                  \
+  hipLaunchKernelGGL(kernel_block_wave_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u, B, \
+                     ldb, (int)v, (int)p, (const double*)pna, (const double*)pnb, -1.0 / sigma, out,  \
+                     ldo, diag_shift, tiles_m, ntiles)
+    switch (ks) {
+      case 1: BK_KBW(1); break;
+      case 2: BK_KBW(2); break;
+      case 3: BK_KBW(3); break;
+      case 4: BK_KBW(4); break;
+      case 5: BK_KBW(5); break;
+      case 6: BK_KBW(6); break;
+      case 7: BK_KBW(7); break;
+      default: BK_KBW(8); break;
+    }
+#undef BK_KBW
+    BK_CHECK_LAUNCH();
+    BK_TRY(prof_end(ctx, "kernel_block"));
+    return BIGKRLS_OK;
+  }
   GemmOperands g{A, B, lda, ldb, (int)u, (int)v, (int)p, nullptr};
   constexpr int KBN = 64;
   const int tiles_m = (int)((u + BM - 1) / BM), tiles_n = (int)((v + KBN - 1) / KBN);

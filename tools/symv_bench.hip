@@ -63,8 +63,9 @@ int main(int argc, char** argv) {
   const int vec = 2, CH = 64 * vec;
   const int nstrips = (L + SV_CW - 1) / SV_CW;
   for (int div : {2, 4, 6, 12, 24}) {
-    int RS = ((L / div + 4 * CH - 1) / (4 * CH)) * (4 * CH);
-    RS = std::max(4 * CH, std::min(RS, 16384));
+    const int rsq = 4 * CH * BK_SV_NCH;
+    int RS = ((L / div + rsq - 1) / rsq) * rsq;
+    RS = std::max(rsq, std::min(RS, 16384));
     const int nsegmax = (L + 1 + RS - 1) / RS;
     char nm[64]; snprintf(nm, 64, "tiled symv RS=%d", RS);
     timeit(nm, 4.0 * L * (L + 1.0), [&] {
@@ -73,7 +74,7 @@ int main(int argc, char** argv) {
     if (nsegmax > 9) break;
   }
   {
-    int RS = ((L / 6 + 4 * CH - 1) / (4 * CH)) * (4 * CH); RS = std::max(4 * CH, std::min(RS, 8192));
+    const int rsq = 4 * CH * BK_SV_NCH; int RS = ((L / 6 + rsq - 1) / rsq) * rsq; RS = std::max(rsq, std::min(RS, 8192));
     const int nq = (nstrips + 31) / 32, nb3 = (L + 255) / 256;
     timeit("symv_reduce", 8.0 * L * nstrips / 2, [&] {
       trd_symv_reduce<<<dim3(nb3, nq), 256, 0, st>>>(W, n, c, i, pw, RS, vec, part1, nb1, sw.Prow, sw.Pcol, sw.Prow2, P1, P2);
