@@ -84,6 +84,7 @@ enum Slot {
   SLOT_EIG_BT = 18,
   SLOT_EIG_Z = 19,
   SLOT_EIG_DESC = 20,
+  SLOT_EIG_VV = 21,
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

@@ -1241,6 +1241,8 @@ int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, 
   return BIGKRLS_OK;
 }
 
+#include "eigen_2stage.inc"
+
 }  // namespace
 
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
@@ -1273,8 +1275,49 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
             (double*)pU + sv_prow + sv_pcol + sv_prow2};
   const char* symv_env = getenv("BIGKRLS_SYMV");
   const bool tiled = !(symv_env && std::string(symv_env) == "full");
-  if (n >= 2) BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw, tiled));
-  else BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
+  // two-stage (band) reduction: opt-in via BIGKRLS_EIG=2stage while it is being tuned
+  const char* eig_env = getenv("BIGKRLS_EIG");
+  const bool two_stage = eig_env && std::string(eig_env) == "2stage" && n > 4 * S2_B;
+  double *taus1 = nullptr, *AB = nullptr, *VV = nullptr, *TT = nullptr;
+  int64_t* d_soff = nullptr;
+  Stage1Ws s1{};
+  if (two_stage) {
+    const int64_t nb64 = N * S2_B;
+    void *p2 = nullptr, *pvv = nullptr;
+    const int64_t maxb = (N + 255) / 256 + 2;
+    const int64_t npart = 2 * maxb + (N / PQ_RC + 3) * S2_B + S2_B;
+    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + N /*taus1*/ +
+                         (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
+    BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p2));
+    double* q = (double*)p2;
+    s1.Vp = q; q += nb64;
+    s1.Y = q; q += nb64;
+    s1.Y2 = q; q += nb64;
+    s1.PZ1 = q; q += 2 * nb64;
+    s1.PZ2 = q; q += 2 * nb64;
+    s1.small = q; q += 8 * S2_B * S2_B;
+    s1.part = q; q += npart;
+    taus1 = q; q += N;
+    AB = q; q += (int64_t)S2_LD * N;
+    d_soff = (int64_t*)q;
+    Stage2Plan plan = stage2_plan(n);
+    BK_TRY(ws_get(ctx, SLOT_EIG_VV, (plan.nrefl * (S2_B + 1) + 16) * sizeof(double), &pvv));
+    VV = (double*)pvv;
+    TT = VV + plan.nrefl * S2_B;
+    BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
+                          hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemsetAsync(taus1, 0, N * sizeof(double), st));
+    BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
+    int blocks = (int)std::min<int64_t>(((int64_t)S2_LD * N + 255) / 256, 8192);
+    hipLaunchKernelGGL(s1_extract_band, dim3(blocks), dim3(256), 0, st, (const double*)W, n, AB);
+    BK_CHECK_LAUNCH();
+    BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e));
+    BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
+  } else if (n >= 2) {
+    BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw, tiled));
+  } else {
+    BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   std::vector<double> hd(n), he(n);
   BK_HIP(hipMemcpyAsync(hd.data(), d, N * sizeof(double), hipMemcpyDeviceToHost, st));
   BK_HIP(hipMemcpyAsync(he.data(), e, N * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1303,7 +1346,15 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     hipLaunchKernelGGL(gather_cols, dim3(blocks), dim3(256), 0, st, n, nv, (const int*)d_src,
                        (const double*)Qfin, N, vecs, ldv);
     BK_CHECK_LAUNCH();
-    BK_TRY(back_transform(ctx, W, n, tau, vecs, ldv, nv));
+    if (two_stage) {
+      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, vecs, ldv, nv));
+      void* pw12 = nullptr;
+      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * nv * sizeof(double), &pw12));
+      BK_TRY(back_transform_stage1(ctx, W, n, taus1, vecs, ldv, nv, s1.Vp, s1.small, (double*)pw12,
+                                   (double*)pw12 + (int64_t)S2_B * nv));
+    } else {
+      BK_TRY(back_transform(ctx, W, n, tau, vecs, ldv, nv));
+    }
   }
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
