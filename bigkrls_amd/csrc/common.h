@@ -105,6 +105,9 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                const double* B, int64_t ldb, double* C, int64_t ldc);
 
+int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                const double* B, int64_t ldb, double* C, int64_t ldc);
+
 // batched GEMM for the divide & conquer merges: per-problem descriptors on device
 struct GemmDesc {
   const double* A;

@@ -1286,7 +1286,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     void *p2 = nullptr, *pvv = nullptr;
     const int64_t maxb = (N + 255) / 256 + 2;
     const int64_t npart = 2 * maxb + (N / PQ_RC + 3) * S2_B + S2_B;
-    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + N /*taus1*/ +
+    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
     BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p2));
     double* q = (double*)p2;
@@ -1297,7 +1297,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     s1.PZ2 = q; q += 2 * nb64;
     s1.small = q; q += 8 * S2_B * S2_B;
     s1.part = q; q += npart;
-    taus1 = q; q += N;
+    taus1 = q; q += 2 * N;
     AB = q; q += (int64_t)S2_LD * N;
     d_soff = (int64_t*)q;
     Stage2Plan plan = stage2_plan(n);
@@ -1306,7 +1306,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     TT = VV + plan.nrefl * S2_B;
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemsetAsync(taus1, 0, N * sizeof(double), st));
+    BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
     BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
     int blocks = (int)std::min<int64_t>(((int64_t)S2_LD * N + 255) / 256, 8192);
     hipLaunchKernelGGL(s1_extract_band, dim3(blocks), dim3(256), 0, st, (const double*)W, n, AB);

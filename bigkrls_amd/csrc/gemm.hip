@@ -369,6 +369,77 @@ __global__ __launch_bounds__(NT) void syrk_lower_kernel(GemmOperands g, double a
   });
 }
 
+// Same lower-triangular tile set, but the updated values are also mirrored into the upper
+// triangle (through a per-wave 16 x 16 LDS transpose so that the mirrored stores are 128-byte
+// segments too): C stays a fully stored, exactly symmetric matrix at half the MFMA work of a
+// full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
+__global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double alpha,
+                                                         double* __restrict__ C, int64_t ldc,
+                                                         int tiles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int t = blockIdx.x;
+  int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t)) * 0.5);
+  while (tn > 0 && tn * tiles - tn * (tn - 1) / 2 > t) --tn;
+  while ((tn + 1) * tiles - (tn + 1) * tn / 2 <= t) ++tn;
+  const int tm = tn + (t - (tn * tiles - tn * (tn - 1) / 2));
+  const int m0 = tm * BM, n0 = tn * 128;
+  d4 acc[4][4];
+  gemm_tile<false, true, 128>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
+  const int M = g.M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int lm = lane & 15, lk = lane >> 4;
+  double* buf = smem + wave * (16 * 17);
+  const bool diag_tile = (tm == tn);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mt0 = m0 + wm + i * 16, nt0 = n0 + wn + j * 16;  // 16 x 16 sub-tile origin
+      if (diag_tile && mt0 + 15 < nt0) continue;                  // entirely above the diagonal
+      const int m = mt0 + lm;
+      double vals[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt0 + lk + 4 * r;
+        double v = 0.0;
+        if (m < M && n < M && m >= n) {
+          const int64_t o = (int64_t)m + (int64_t)n * ldc;
+          v = C[o] + alpha * acc[i][j][r];
+          C[o] = v;
+        }
+        vals[r] = v;
+        buf[(lk + 4 * r) * 17 + lm] = v;   // buf[n_local][m_local]
+      }
+      // mirrored store: lane' -> (n' = nt0 + lm, m' = mt0 + lk + 4 r')
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = mt0 + lk + 4 * r, nn = nt0 + lm;
+        const double v = buf[lm * 17 + (lk + 4 * r)];
+        if (mm < M && nn < M && mm > nn) C[(int64_t)nn + (int64_t)mm * ldc] = v;
+      }
+    }
+}
+
+int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                const double* B, int64_t ldb, double* C, int64_t ldc) {
+  if (m <= 0 || k <= 0) return BIGKRLS_OK;
+  BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror: dimension too large");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
+  const int tiles = (int)((m + BM - 1) / BM);
+  const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BK_HIP(hipFuncSetAttribute((const void*)syrk_mirror_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(syrk_mirror_kernel, dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
+                     alpha, C, ldc, tiles);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                const double* B, int64_t ldb, double* C, int64_t ldc) {
   if (m <= 0 || k <= 0) return BIGKRLS_OK;
