@@ -141,15 +141,54 @@ def main():
         dt = float(tmax.item())
     sec_per_fit = dt / args.steps
 
-    symv_ms, symv_bytes, symv_n = ctx.get_profile("symv")
-    kb_ms, kb_flops, kb_n = ctx.get_profile("kernel_block")
-    tu_ms, tu_flops, tu_n = ctx.get_profile("trailing_update")
+    prof = {name: ctx.get_profile(name) for name in
+            ("symv", "kernel_block", "trailing_update", "band_update", "band_av")}
     ctx.set_profile(False)
 
     if rank == 0:
         n, p = args.n, args.p
         phases = {k: round(v / args.steps, 4) for k, v in phase_sum.items()}
-        symv_gbs = (symv_bytes / 1e9) / (symv_ms / 1e3) if symv_ms > 0 else 0.0
+        kb_ms, kb_flops, kb_n = prof["kernel_block"]
+
+        def mfma_entry(name, kernel, note):
+            ms, fl, cnt = prof[name]
+            if ms <= 0:
+                return None
+            tf = fl / (ms / 1e3) / 1e12
+            return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
+                    "total_ms_per_fit": round(ms / args.steps, 2),
+                    "avg_algorithmic_flops_per_launch": round(fl / max(cnt, 1), 0), "note": note}
+
+        def symv_entry():
+            ms, by, cnt = prof["symv"]
+            if ms <= 0:
+                return None
+            gbs = (by / 1e9) / (ms / 1e3)
+            return {"kernel": "trd_symv_tiles(+trd_symv_reduce): Householder symv over the lower triangle of "
+                              "the trailing matrix (one-stage tridiagonalisation, BIGKRLS_EIG=1stage)",
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": symv_traffic(by, cnt),
+                    "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
+                    "total_ms_per_fit": round(ms * 8 / args.steps, 2),
+                    "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
+                    "note": "achieved = 8*L(L+1)/2 algorithmic bytes per launch / HIP-event duration on the launch "
+                            "stream over every 8th column; traffic = algorithmic x the PMC ratio of "
+                            "profiles/r01_symv_pmc.json (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)"}
+
+        cands = [
+            symv_entry(),
+            mfma_entry("band_update", "syrk_mirror_kernel: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
+                       "store (stage 1 of the two-stage tridiagonalisation), one launch per 64-column panel",
+                       "achieved = m(m+1)*2b algorithmic flops per launch (lower triangle incl. diagonal tiles, "
+                       "m = trailing size, b = 64) / HIP-event duration on the launch stream, all launches"),
+            mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
+                       "achieved = 2 m^2 b flops per launch / HIP-event duration"),
+        ]
+        cands = [c for c in cands if c]
+        roof = max(cands, key=lambda c: c["total_ms_per_fit"]) if cands else None
+        tu_ms, tu_flops, tu_n = prof["trailing_update"]
         res = {
             "metric": "bigKRLS_fit_wall_clock_s (full fit, N=20000, P=20, fp64)" if (n, p) == (20000, 20)
                       else f"bigKRLS_fit_wall_clock_s (full fit, N={n}, P={p}, fp64)",
@@ -174,29 +213,15 @@ def main():
                 "tflops": round(kb_flops / (kb_ms / 1e3) / 1e12, 3) if kb_ms > 0 else None,
                 "frac_of_fp64_mfma_peak": round(kb_flops / (kb_ms / 1e3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if kb_ms > 0 else None,
                 "hbm_write_gbs": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3), 1) if kb_ms > 0 else None,
+                "frac_of_hbm_peak": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3) / HBM_PEAK_GBS, 4) if kb_ms > 0 else None,
                 "ms": round(kb_ms / max(kb_n, 1), 4), "launches": kb_n,
-                "note": "2*N^2*P flops / launch; at P=20 the build is HBM-write bound (8 N^2 bytes)"},
-            "trailing_update": {
-                "tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3) if tu_ms > 0 else None,
-                "launches": tu_n},
-            "roofline": {
-                "kernel": "trd_symv_tiles(+trd_symv_reduce): Householder symv over the lower triangle of the "
-                          "trailing matrix, one launch pair per column of the tridiagonalisation",
-                "bound": "hbm",
-                "achieved": round(symv_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(symv_gbs / HBM_PEAK_GBS, 4),
-                "traffic": symv_traffic(symv_bytes, symv_n),
-                "launches_sampled": symv_n,
-                "avg_launch_us": round(symv_ms * 1e3 / max(symv_n, 1), 2),
-                "avg_algorithmic_bytes_per_launch": round(symv_bytes / max(symv_n, 1), 0),
-                "note": "achieved = 8*L(L+1)/2 algorithmic bytes per launch (lower triangle, L = trailing size) "
-                        "/ HIP-event duration on the launch stream, summed over the sampled launches (every 8th "
-                        "column); traffic = avg HBM bytes per launch = algorithmic x the PMC ratio measured in "
-                        "profiles/r01_symv_pmc.json (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, "
-                        "separate passes)"},
+                "note": "kernel_block_wave_kernel: 2*N^2*P flops per launch; at P=20 the build is HBM-write "
+                        "bound (8 N^2 bytes, AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
+            "roofline": roof,
+            "other_kernels": [c for c in cands if c is not roof],
         }
+        if tu_ms > 0:
+            res["trailing_update"] = {"tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3), "launches": tu_n}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(p, args.cpu_n, args.seed)
         print(json.dumps(res))

@@ -1275,9 +1275,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
             (double*)pU + sv_prow + sv_pcol + sv_prow2};
   const char* symv_env = getenv("BIGKRLS_SYMV");
   const bool tiled = !(symv_env && std::string(symv_env) == "full");
-  // two-stage (band) reduction: opt-in via BIGKRLS_EIG=2stage while it is being tuned
+  // two-stage (band) reduction is the default above 4 panels; BIGKRLS_EIG=1stage forces the
+  // one-stage (symv) reduction (kept for small n and as a cross-check: the tests run both)
   const char* eig_env = getenv("BIGKRLS_EIG");
-  const bool two_stage = eig_env && std::string(eig_env) == "2stage" && n > 4 * S2_B;
+  const bool two_stage = !(eig_env && std::string(eig_env) == "1stage") && n > 4 * S2_B;
   double *taus1 = nullptr, *AB = nullptr, *VV = nullptr, *TT = nullptr;
   int64_t* d_soff = nullptr;
   Stage1Ws s1{};

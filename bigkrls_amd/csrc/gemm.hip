@@ -230,12 +230,31 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmOperands g, double alpha, 
         if (m < M && n < N) C[(int64_t)m + (int64_t)n * ldc] = alpha * v;
       });
     } else {
-      acc_foreach<BN>(acc, m0, n0, [&](int m, int n, double v) {
-        if (m < M && n < N) {
-          const int64_t o = (int64_t)m + (int64_t)n * ldc;
-          C[o] = alpha * v + beta * C[o];
-        }
-      });
+      // read-modify-write: fetch every C value of the lane in one batch, then combine and store
+      constexpr int NJ = BN / 32;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
+      const int lm = lane & 15, lk = lane >> 4;
+      d4 cold[4][NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
+            cold[i][j][r] = (m < M && n < N) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
+          }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
+            if (m < M && n < N)
+              C[(int64_t)m + (int64_t)n * ldc] = alpha * acc[i][j][r] + beta * cold[i][j][r];
+          }
     }
   }
 }
@@ -391,6 +410,20 @@ __global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double 
   const int lm = lane & 15, lk = lane >> 4;
   double* buf = smem + wave * (16 * 17);
   const bool diag_tile = (tm == tn);
+  // All 64 C values of this lane are fetched in one batch (one exposed memory latency instead
+  // of sixteen: with one workgroup per CU nothing else would hide them).
+  d4 cold[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm + i * 16 + lm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + j * 16 + lk + 4 * r;
+        cold[i][j][r] = (m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
+      }
+    }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -405,7 +438,7 @@ __global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double 
         double v = 0.0;
         if (m < M && n < M && m >= n) {
           const int64_t o = (int64_t)m + (int64_t)n * ldc;
-          v = C[o] + alpha * acc[i][j][r];
+          v = cold[i][j][r] + alpha * acc[i][j][r];
           C[o] = v;
         }
         vals[r] = v;

@@ -162,9 +162,15 @@ def test_validation_errors(ctx):
         bk.bigKRLS(y, X, derivative=False, which_derivatives=[1], ctx=ctx)
 
 
-def test_fit_medium_n2000(ctx):
-    """Bigger than one tile grid / several reflector panels; default eigtrunc path off (n<=3000)."""
+@pytest.mark.parametrize("path", ["1stage", "2stage"])
+def test_fit_medium_n2000(ctx, monkeypatch, path):
+    """Bigger than one tile grid / several reflector panels; default eigtrunc path off (n<=3000).
+    Both tridiagonalisation paths must give the same fit."""
     import bigkrls_amd as bk
+    if path == "1stage":
+        monkeypatch.setenv("BIGKRLS_EIG", "1stage")
+    else:
+        monkeypatch.delenv("BIGKRLS_EIG", raising=False)
     X, y = orc.synth(2000, 10, 102)
     ref = orc.fit(y, X, literal=False)
     T = {}

@@ -139,8 +139,20 @@ def test_solveforc_matches_literal_row_loop(lib, n, p, trunc):
         assert abs(le.value - le_ref) / le_ref < 1e-9
 
 
-@pytest.mark.parametrize("n,p", [(1, 1), (2, 1), (3, 2), (64, 3), (65, 3), (200, 2), (500, 5), (1000, 10)])
-def test_eigen_full(lib, n, p):
+@pytest.fixture(params=["1stage", "2stage"])
+def eig_path(request, monkeypatch):
+    """Both tridiagonalisation paths: one-stage (symv) and two-stage (band + bulge chasing;
+    the default above 256 rows). The library reads BIGKRLS_EIG at every call."""
+    if request.param == "1stage":
+        monkeypatch.setenv("BIGKRLS_EIG", "1stage")
+    else:
+        monkeypatch.delenv("BIGKRLS_EIG", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (2, 1), (3, 2), (64, 3), (65, 3), (200, 2), (257, 3), (258, 3),
+                                 (321, 4), (385, 2), (500, 5), (1000, 10), (1283, 6)])
+def test_eigen_full(lib, eig_path, n, p):
     X, y = orc.synth(max(n, 2), p, 9)
     X = X[:n]
     K = orc.gauss_kernel_literal(X, float(p))
@@ -156,8 +168,8 @@ def test_eigen_full(lib, n, p):
     assert np.max(np.abs(K @ vecs - vecs * vals)) / scale < 1e-11
 
 
-@pytest.mark.parametrize("n,p,neig", [(300, 4, 10), (500, 5, 50), (400, 3, 399)])
-def test_eigen_partial(lib, n, p, neig):
+@pytest.mark.parametrize("n,p,neig", [(300, 4, 10), (500, 5, 50), (400, 3, 399), (900, 7, 64)])
+def test_eigen_partial(lib, eig_path, n, p, neig):
     """Neig < N takes the reference's eigs_sym branch (src/eigen.cpp:18-22)."""
     X, y = orc.synth(n, p, 10)
     K = orc.gauss_kernel_literal(X, float(p))
@@ -172,9 +184,9 @@ def test_eigen_partial(lib, n, p, neig):
     assert np.max(np.abs(K @ vecs - vecs * vals)) / scale < 1e-11
 
 
-def test_eigen_diagonal_and_degenerate(lib):
+@pytest.mark.parametrize("n", [37, 300])
+def test_eigen_diagonal_and_degenerate(lib, eig_path, n):
     """All-deflated merges (diagonal input) and exactly repeated eigenvalues."""
-    n = 37
     d = np.linspace(1, 2, n)
     vals = np.zeros(n)
     vecs = F(np.zeros((n, n)))
