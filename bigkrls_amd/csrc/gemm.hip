@@ -37,7 +37,7 @@ __device__ __forceinline__ int lds_idx(int k, int x) {
 
 // Load a W x 16 operand tile into registers. Element (x, k) lives at
 // src[x*sx + k*sk]; CONTIG_X says which of the two strides is 1.
-template <bool CONTIG_X, int W>
+template <bool CONTIG_X, int W, bool GATHER = false>
 __device__ __forceinline__ void tile_load(const double* __restrict__ src, int64_t ld, int x0,
                                           int k0, int xmax, int kmax, double (&r)[W / 16],
                                           const int* __restrict__ kidx = nullptr) {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ src, int64_
       const int gx = x0 + x, gk = k0 + k;
       double v = 0.0;
       if (gx < xmax && gk < kmax) {
-        const int64_t col = kidx ? (int64_t)kidx[gk] : (int64_t)gk;
+        const int64_t col = GATHER ? (int64_t)kidx[gk] : (int64_t)gk;
         v = src[(int64_t)gx + col * ld];
       }
       r[q] = v;
@@ -96,7 +96,7 @@ struct GemmOperands {
 
 // Computes the accumulators of the (m0, n0) block tile over k in [kbeg, kend).
 // TA/TB: operand is used transposed (op(A) = A' with A stored K x M, etc.).
-template <bool TA, bool TB, int BN>
+template <bool TA, bool TB, int BN, bool GATHER = false>
 __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0, int kbeg,
                                           int kend, double* __restrict__ smem,
                                           d4 (&acc)[4][BN / 32]) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
   const int ntiles = (kend - kbeg + BK - 1) / BK;
   if (ntiles <= 0) return;
 
-  tile_load<A_CONTIG, BM>(g.A, g.lda, m0, kbeg, g.M, kend, ra, g.kidx);
+  tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, kbeg, g.M, kend, ra, g.kidx);
   tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
   tile_store<A_CONTIG, BM>(As[0], ra);
   tile_store<B_CONTIG, BN>(Bs[0], rb);
@@ -135,7 +135,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
     const int cur = t & 1;
     if (t + 1 < ntiles) {
       const int k0 = kbeg + (t + 1) * BK;
-      tile_load<A_CONTIG, BM>(g.A, g.lda, m0, k0, g.M, kend, ra, g.kidx);
+      tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, k0, g.M, kend, ra, g.kidx);
       tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, k0, g.N, kend, rb);
     }
     const double* as = As[cur];
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NT) void gemm_batched_nn_kernel(const GemmDesc* __r
   if (m0 >= d.m || n0 >= d.n) return;
   GemmOperands g{d.A, d.B, d.lda, d.ldb, d.m, d.n, d.k, d.kidx};
   d4 acc[4][4];
-  gemm_tile<false, false, 128>(g, m0, n0, 0, d.k, smem, acc);
+  gemm_tile<false, false, 128, true>(g, m0, n0, 0, d.k, smem, acc);
   double* C = d.C;
   const int64_t ldc = d.ldc;
   const int M = d.m, N = d.n;

@@ -1,0 +1,38 @@
+// GEMM core micro-benchmark (development tool)
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_bench.hip -o tools/gemm_bench -Lbigkrls_amd -lbigkrls_hip -Wl,-rpath,'$ORIGIN/../bigkrls_amd'
+#include "../bigkrls_amd/csrc/common.h"
+#include <cstdio>
+#include <cstdlib>
+using namespace bk;
+__global__ void fillr(double* p, int64_t n, unsigned seed) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)e * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[e] = (double)(x & 0xffff) / 65536.0 - 0.5;
+  }
+}
+int main(int argc, char** argv) {
+  bigkrls_ctx* ctx; if (bigkrls_ctx_create(0, &ctx)) { printf("%s\n", bigkrls_last_error()); return 1; }
+  hipStream_t st = ctx->stream;
+  const int64_t n = argc > 1 ? atoll(argv[1]) : 20000;
+  double *C, *A, *B; hipMalloc(&C, n * n * 8); hipMalloc(&A, n * 256 * 8); hipMalloc(&B, n * 256 * 8);
+  fillr<<<2048, 256, 0, st>>>(C, n * n, 1); fillr<<<2048, 256, 0, st>>>(A, n * 256, 2); fillr<<<2048, 256, 0, st>>>(B, n * 256, 3);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char* name, double flops, auto fn) {
+    fn(); hipStreamSynchronize(st);
+    hipEventRecord(e0, st); const int reps = 3;
+    for (int r = 0; r < reps; ++r) fn();
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("%-44s %9.1f us  %7.2f TFLOP/s\n", name, ms * 1e3, flops / (ms * 1e-3) / 1e12);
+  };
+  timeit("syrk_mirror m=n k=128", (double)n * (n + 1) * 128, [&] { syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n); });
+  timeit("syrk_lower  m=n k=128", (double)n * (n + 1) * 128, [&] { syrk_lower(ctx, n, 128, -1.0, A, n, B, n, C, n); });
+  timeit("gemm NT m=n=n k=128 beta=1", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 1.0, C, n); });
+  timeit("gemm NT m=n=n k=128 beta=0", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 0.0, C, n); });
+  timeit("gemm NN (n x 64) = C(n x n) * A(n x 64)", 2.0 * n * n * 64, [&] { gemm(ctx, 0, 0, n, 64, n, 1.0, C, n, A, n, 0.0, B, n); });
+  const int64_t q = 8192;
+  timeit("gemm NN 8192^3", 2.0 * q * q * q, [&] { gemm(ctx, 0, 0, q, q, q, 1.0, C, q, C + q * q, q, 0.0, C + 2 * q * q, q); });
+  timeit("gemm NT 8192^3", 2.0 * q * q * q, [&] { gemm(ctx, 0, 1, q, q, q, 1.0, C, q, C + q * q, q, 0.0, C + 2 * q * q, q); });
+  timeit("gemm TN 8192^3", 2.0 * q * q * q, [&] { gemm(ctx, 1, 0, q, q, q, 1.0, C, q, C + q * q, q, 0.0, C + 2 * q * q, q); });
+  return 0;
+}
