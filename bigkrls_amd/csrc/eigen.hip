@@ -1190,15 +1190,21 @@ __global__ __launch_bounds__(64) void bt_build_t(const double* __restrict__ G, i
                                                  const double* __restrict__ tau,
                                                  double* __restrict__ T) {
   __shared__ double sT[TRD_NB * TRD_NB];
+  __shared__ double sG[TRD_NB * TRD_NB];
+  __shared__ double stau[TRD_NB];
   const int t = threadIdx.x;
-  for (int e = t; e < pw * pw; e += 64) sT[e] = 0.0;
+  for (int e = t; e < pw * pw; e += 64) {
+    sT[e] = 0.0;
+    sG[e] = G[e];   // one batch of global loads instead of a dependent load per inner step
+  }
+  if (t < pw) stau[t] = tau[t];
   __syncthreads();
   for (int i = 0; i < pw; ++i) {
-    const double ti = tau[i];
+    const double ti = stau[i];
     // T[0:i, i] = -tau_i * T[0:i,0:i] * G[0:i, i]
     double acc = 0.0;
     if (t < i) {
-      for (int k = t; k < i; ++k) acc += sT[t + k * pw] * G[k + i * pw];  // upper triangular rows
+      for (int k = t; k < i; ++k) acc += sT[t + k * pw] * sG[k + i * pw];  // upper triangular rows
       acc *= -ti;
     }
     __syncthreads();
@@ -1287,7 +1293,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     void *p2 = nullptr, *pvv = nullptr;
     const int64_t maxb = (N + 255) / 256 + 2;
     const int64_t npart = 2 * maxb + (N / PQ_RC + 3) * S2_B + S2_B;
-    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + 2 * N /*taus1, scales1*/ +
+    const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
+    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
     BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p2));
     double* q = (double*)p2;
@@ -1298,6 +1305,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     s1.PZ2 = q; q += 2 * nb64;
     s1.small = q; q += 8 * S2_B * S2_B;
     s1.part = q; q += npart;
+    s1.Tall = q; q += ntall;
     taus1 = q; q += 2 * N;
     AB = q; q += (int64_t)S2_LD * N;
     d_soff = (int64_t*)q;
@@ -1351,7 +1359,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, vecs, ldv, nv));
       void* pw12 = nullptr;
       BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * nv * sizeof(double), &pw12));
-      BK_TRY(back_transform_stage1(ctx, W, n, taus1, vecs, ldv, nv, s1.Vp, s1.small, (double*)pw12,
+      BK_TRY(back_transform_stage1(ctx, W, n, taus1, vecs, ldv, nv, s1.Vp, s1.Tall, (double*)pw12,
                                    (double*)pw12 + (int64_t)S2_B * nv));
     } else {
       BK_TRY(back_transform(ctx, W, n, tau, vecs, ldv, nv));
