@@ -112,109 +112,6 @@ __global__ __launch_bounds__(256) void trd_k1(double* __restrict__ W, int n, int
   if (tid == 0) part1[blockIdx.x] = ss;
 }
 
-// K2: Householder scalars (recomputed identically by every block), y = A22' v,
-// panel dots t1 = Wm' v, t2 = V' v, and v stored into the panel.
-__global__ __launch_bounds__(256) void trd_k2(const double* __restrict__ W, int n, int c, int i,
-                                              int pw, double* __restrict__ P1,
-                                              double* __restrict__ P2,
-                                              const double* __restrict__ part1, int np1,
-                                              double* __restrict__ y, double* __restrict__ tvec,
-                                              double* __restrict__ e, double* __restrict__ tau) {
-  __shared__ double s_scale;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t N = n;
-  const int L = n - c - 1;
-  const double* x = W + (c + 1) + (int64_t)c * N;
-  if (tid == 0) {
-    double ss = 0.0;
-    for (int q = 0; q < np1; ++q) ss += part1[q];
-    const double alpha = x[0];
-    double beta, t, sc;
-    if (ss == 0.0) {
-      beta = alpha; t = 0.0; sc = 0.0;
-    } else {
-      beta = -copysign(hypot(alpha, sqrt(ss)), alpha);
-      t = (beta - alpha) / beta;
-      sc = 1.0 / (alpha - beta);
-    }
-    s_scale = sc;
-    if (blockIdx.x == 0) { e[c] = beta; tau[c] = t; }
-  }
-  __syncthreads();
-  const double scale = s_scale;
-  // four columns per wave
-  const int q0 = (blockIdx.x * 4 + wave) * 4;
-  const int total = L + 2 * i;
-  const double* ptr[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int q = q0 + u;
-    if (q < L) ptr[u] = W + (c + 1) + (int64_t)(c + 1 + q) * N;
-    else if (q < L + i) ptr[u] = P1 + (c + 1) + (int64_t)(pw + (q - L)) * N;
-    else if (q < total) ptr[u] = P1 + (c + 1) + (int64_t)(q - L - i) * N;
-    else ptr[u] = nullptr;
-  }
-  if (q0 < total) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = lane; r < L; r += 64) {
-      const double v = (r == 0) ? 1.0 : x[r] * scale;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ptr[u]) acc[u] += ptr[u][r] * v;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double s = wsum(acc[u]);
-      const int q = q0 + u;
-      if (lane == 0 && q < total) {
-        if (q < L) y[q] = s;
-        else tvec[q - L] = s;   // [0,i): Wm'v ; [i,2i): V'v
-      }
-    }
-  }
-  // store v into the panel (first ceil(L/256) blocks)
-  const int r = blockIdx.x * 256 + tid;
-  if (r < L) {
-    const double v = (r == 0) ? 1.0 : x[r] * scale;
-    P1[(c + 1 + r) + (int64_t)i * N] = v;
-    P2[(c + 1 + r) + (int64_t)(pw + i) * N] = v;
-  }
-}
-
-// K3: w~ = tau (y - V (Wm'v) - Wm (V'v)), partial w~'v, reflector stored in place
-__global__ __launch_bounds__(256) void trd_k3(double* __restrict__ W, int n, int c, int i, int pw,
-                                              double* __restrict__ P1, double* __restrict__ P2,
-                                              const double* __restrict__ y,
-                                              const double* __restrict__ tvec,
-                                              const double* __restrict__ tau,
-                                              double* __restrict__ part2) {
-  __shared__ double st1[TRD_NB], st2[TRD_NB], sh[4];
-  const int tid = threadIdx.x;
-  const int64_t N = n;
-  const int L = n - c - 1;
-  if (tid < i) {
-    st1[tid] = tvec[tid];
-    st2[tid] = tvec[i + tid];
-  }
-  __syncthreads();
-  const int r = blockIdx.x * 256 + tid;
-  double pv = 0.0;
-  if (r < L) {
-    const int64_t row = c + 1 + r;
-    const double v = P1[row + (int64_t)i * N];
-    double s = y[r];
-    for (int k = 0; k < i; ++k)
-      s -= P1[row + (int64_t)k * N] * st1[k] + P1[row + (int64_t)(pw + k) * N] * st2[k];
-    const double wt = tau[c] * s;
-    P1[row + (int64_t)(pw + i) * N] = wt;
-    P2[row + (int64_t)i * N] = wt;
-    W[row + (int64_t)c * N] = v;
-    pv = wt * v;
-  }
-  pv = bsum256(pv, sh);
-  if (tid == 0) part2[blockIdx.x] = pv;
-}
-
 // finalise the last w column of a panel (rows >= row_begin)
 __global__ __launch_bounds__(256) void trd_fin(int n, int c, int i, int pw,
                                                double* __restrict__ P1, double* __restrict__ P2,
@@ -536,7 +433,7 @@ struct SymvWs {
 
 int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, double* tau,
                    double* P1, double* P2, double* scratch /* y[n] + tvec[2nb] + part1 + part2 */,
-                   const SymvWs& sw, bool tiled) {
+                   const SymvWs& sw) {
   const int maxb = (n + 255) / 256 + 1;
   double* y = scratch;
   double* tvec = y + n;
@@ -557,15 +454,7 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
       const int L = n - c - 1;
       const int nb3 = (L + 255) / 256;
       const bool sample = ctx->profile && (c % 8 == 0);
-      if (!tiled) {
-        const int nb2 = (L + 2 * i + 15) / 16;
-        if (sample) BK_TRY(prof_begin(ctx, "symv", 4.0 * (double)L * (double)(L + 1)));
-        hipLaunchKernelGGL(trd_k2, dim3(nb2), dim3(256), 0, st, (const double*)W, n, c, i, pw, P1, P2,
-                           (const double*)part1, nb1, y, tvec, e, tau);
-        if (sample) BK_TRY(prof_end(ctx, "symv"));
-        hipLaunchKernelGGL(trd_k3, dim3(nb3), dim3(256), 0, st, W, n, c, i, pw, P1, P2,
-                           (const double*)y, (const double*)tvec, (const double*)tau, part2);
-      } else {
+      {
         const int nstrips = (L + SV_CW - 1) / SV_CW;
         const int rsq = 4 * CH * BK_SV_NCH;  // segments are whole numbers of block iterations
         int RS = ((L / 6 + rsq - 1) / rsq) * rsq;
@@ -603,12 +492,8 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
     BK_CHECK_LAUNCH();
     const int64_t mt = n - j1;
     BK_TRY(prof_begin(ctx, "trailing_update",
-                      (tiled ? (double)mt * (double)(mt + 1) : 2.0 * (double)mt * (double)mt) * 2.0 * pw));
-    if (tiled)
-      BK_TRY(syrk_lower(ctx, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, W + j1 + (int64_t)j1 * N, N));
-    else
-      BK_TRY(gemm(ctx, 0, 1, mt, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, 1.0,
-                  W + j1 + (int64_t)j1 * N, N));
+                      (double)mt * (double)(mt + 1) * 2.0 * pw));
+    BK_TRY(syrk_lower(ctx, mt, 2 * pw, -1.0, P1 + j1, N, P2 + j1, N, W + j1 + (int64_t)j1 * N, N));
     BK_TRY(prof_end(ctx, "trailing_update"));
   }
   BK_HIP(hipMemcpyAsync(d + (n - 1), W + (int64_t)(n - 1) * N + (n - 1), sizeof(double),
@@ -1279,8 +1164,6 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   BK_TRY(ws_get(ctx, SLOT_EIG_U, u_doubles * sizeof(double), &pU));
   SymvWs sw{(double*)pU, (double*)pU + sv_prow, (double*)pU + sv_prow + sv_pcol,
             (double*)pU + sv_prow + sv_pcol + sv_prow2};
-  const char* symv_env = getenv("BIGKRLS_SYMV");
-  const bool tiled = !(symv_env && std::string(symv_env) == "full");
   // two-stage (band) reduction is the default above 4 panels; BIGKRLS_EIG=1stage forces the
   // one-stage (symv) reduction (kept for small n and as a cross-check: the tests run both)
   const char* eig_env = getenv("BIGKRLS_EIG");
@@ -1323,7 +1206,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
   } else if (n >= 2) {
-    BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw, tiled));
+    BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw));
   } else {
     BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
   }

@@ -710,95 +710,6 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
     }
 }
 
-// Tall variant of the same idea: a wave owns 64 rows x 16 columns (4 x 1 MFMA tiles), the
-// four waves of a block are stacked along the rows (256 x 16), and the XCD-aware block
-// order keeps vertically adjacent blocks on the same XCD. Every column of the output is
-// then written in 512-byte (wave) / 2-KB (block) contiguous runs -- HBM pages see long
-// bursts instead of isolated 128-byte lines.
-template <int KS>
-__global__ __launch_bounds__(NT) void kernel_block_tall_kernel(
-    const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V,
-    int P, const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma,
-    double* __restrict__ out, int64_t ldo, int64_t diag_shift, int blocks_m, int nblocks) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bid = xcd_remap(blockIdx.x, nblocks);
-  const int bm = bid % blocks_m, bn = bid / blocks_m;
-  const int m0 = bm * 256 + wave * 64, n0 = bn * 16;
-  if (m0 >= U) return;
-  const int lm = lane & 15, lk = lane >> 4;
-  d4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* ap[4];
-  double nam[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mi = min(m0 + 16 * i + lm, U - 1);
-    ap[i] = A + mi;
-    nam[i] = na[mi];
-  }
-  const double* bp = B + min(n0 + lm, V - 1);
-  double nbv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) nbv[r] = nb[min(n0 + lk + 4 * r, V - 1)];
-  for (int kc0 = 0; kc0 < P; kc0 += 4 * KS) {
-    double fa[4][KS], fb[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int64_t kc = min(kc0 + 4 * s + lk, P - 1);
-      fb[s] = bp[kc * ldb];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i][s] = ap[i][kc * lda];
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const bool kv = (kc0 + 4 * s + lk) < P;
-      const double b = kv ? fb[s] : 0.0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, kv ? fa[i][s] : 0.0, acc[i], 0, 0, 0);
-    }
-  }
-  const bool odd = (lane & 1) != 0;
-  const bool vec_ok = ((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-  for (int rp = 0; rp < 4; rp += 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + i * 16 + lm;
-      double kv[2];
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int n = n0 + lk + 4 * (rp + rr);
-        double d2 = nam[i] + nbv[rp + rr] - 2.0 * acc[i][rp + rr];
-        d2 = d2 > 0.0 ? d2 : 0.0;
-        double e = exp_nonpos(d2 * neg_inv_sigma);
-        if (diag_shift >= 0 && (int64_t)m == (int64_t)n + diag_shift) e = 1.0;
-        kv[rr] = e;
-      }
-      if (vec_ok) {
-        const double send = odd ? kv[0] : kv[1];
-        const double recv = __shfl_xor(send, 1, 64);
-        const double lo = odd ? recv : kv[0];
-        const double hi = odd ? kv[1] : recv;
-        const int mrow = m & ~1;
-        const int n = n0 + lk + 4 * (rp + (odd ? 1 : 0));
-        if (n < V) {
-          double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
-          if (mrow + 1 < U) *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
-          else if (mrow < U) dst[0] = lo;
-        }
-      } else {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int n = n0 + lk + 4 * (rp + rr);
-          if (m < U && n < V) out[(int64_t)m + (int64_t)n * ldo] = kv[rr];
-        }
-      }
-    }
-  }
-}
-
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift) {
@@ -819,11 +730,7 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
     const int steps = (int)((p + 3) / 4);
     const int chunks = (steps + 7) / 8;
     const int ks = (steps + chunks - 1) / chunks;  // 1..8 MFMA steps per chunk, minimal padding
-    (void)ntiles;
-    const int blocks_m = (int)((u + 255) / 256), blocks_n = (int)((v + 15) / 16);
-    const int64_t nblk = (int64_t)blocks_m * blocks_n;
-    BK_REQUIRE(nblk < (1ll << 31), "kernel_block: too many tiles");
-    (void)nblk; (void)blocks_m;
+    BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
     const dim3 grid((unsigned)((ntiles + 3) / 4));
 #define BK_KBW(KS)                                                                                  \
   hipLaunchKernelGGL(kernel_block_wave_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u, B, \

@@ -56,10 +56,6 @@ int main(int argc, char** argv) {
   double* out; hipMalloc(&out, 8);
   timeit("stream read (full matrix)", 8.0 * N * N, [&] { read_bw<<<2048, 256, 0, st>>>((const double2*)W, N * N / 2, out); });
   timeit("stream read (half)", 4.0 * N * N, [&] { read_bw<<<2048, 256, 0, st>>>((const double2*)W, N * N / 4, out); });
-  timeit("old full symv (trd_k2)", 8.0 * L * L, [&] {
-    const int nb2 = (L + 2 * i + 15) / 16;
-    trd_k2<<<nb2, 256, 0, st>>>(W, n, c, i, pw, P1, P2, part1, nb1, y, tvec, e, tau);
-  });
   const int vec = 2, CH = 64 * vec;
   const int nstrips = (L + SV_CW - 1) / SV_CW;
   for (int div : {2, 4, 6, 12, 24}) {
