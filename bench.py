@@ -10,9 +10,10 @@ timed region starts (the N x P input is 3.2 MB; the PCIe-inclusive figure is in
 DESIGN.md).  Rank 0 prints ONE JSON line.  For N > 1 the same fit is row-block
 partitioned over the ranks (strong scaling): see bigkrls_amd/dist.py.
 
-`roofline` is for the dominant kernel of the fit (the Householder symv of the
-tridiagonalisation, HBM-bound), measured live with HIP events on the launch
-stream; `kernel_gemm` reports the Gaussian-kernel GEMM the metric also names.
+`roofline` is for the dominant kernel of the fit -- whichever of the profiled
+eigensolver kernels (bulge chasing, the stage-1 band update / A22 V GEMMs, or the
+one-stage symv) takes the most time -- measured live with HIP events on the
+launch stream; `kernel_gemm` reports the Gaussian-kernel GEMM the metric names.
 `cpu_baseline` times the oracle's literal restatement of the reference on the
 host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -142,7 +143,7 @@ def main():
     sec_per_fit = dt / args.steps
 
     prof = {name: ctx.get_profile(name) for name in
-            ("symv", "kernel_block", "trailing_update", "band_update", "band_av")}
+            ("symv", "kernel_block", "trailing_update", "band_update", "band_av", "bulge_chase")}
     ctx.set_profile(False)
 
     if rank == 0:
@@ -177,8 +178,27 @@ def main():
                             "stream over every 8th column; traffic = algorithmic x the PMC ratio of "
                             "profiles/r01_symv_pmc.json (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)"}
 
+        def bulge_entry():
+            ms, by, cnt = prof["bulge_chase"]
+            if ms <= 0:
+                return None
+            gbs = (by / 1e9) / (ms / 1e3)
+            return {"kernel": "bc_wavefront: one anti-diagonal wavefront of bulge-chasing tasks (stage 2 of the "
+                              "two-stage tridiagonalisation, band b=64 -> tridiagonal), ~2N launches per fit",
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
+                    "total_ms_per_fit": round(ms * 64 / args.steps, 2),
+                    "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
+                    "note": "achieved = algorithmic bytes per launch (each task reads+writes its 64x64 off-diagonal "
+                            "block and the lower triangle of its 64x64 diagonal block: 98.8 KB per task, <= N/127 "
+                            "tasks per launch) / HIP-event duration on the launch stream, every 64th launch sampled. "
+                            "The band (16 N b bytes = 20 MB) stays in L2/MALL, so the kernel is bound by the "
+                            "dependent-launch latency of the 2N-long wavefront chain, not by HBM bandwidth"}
+
         cands = [
             symv_entry(),
+            bulge_entry(),
             mfma_entry("band_update", "syrk_mirror_kernel: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
                        "store (stage 1 of the two-stage tridiagonalisation), one launch per 64-column panel",
                        "achieved = m(m+1)*2b algorithmic flops per launch (lower triangle incl. diagonal tiles, "

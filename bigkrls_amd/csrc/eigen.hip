@@ -1175,7 +1175,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int64_t nb64 = N * S2_B;
     void *p2 = nullptr, *pvv = nullptr;
     const int64_t maxb = (N + 255) / 256 + 2;
-    const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B;
+    const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N;
     const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
     const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;

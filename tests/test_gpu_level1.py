@@ -231,3 +231,21 @@ def test_error_reporting(lib):
     out = F(np.zeros((4, 4)))
     st = lib.bigkrls_gauss_kernel(P(X), 4, 2, -1.0, P(out))
     assert st == 1 and b"sigma" in lib.bigkrls_last_error()
+
+
+@pytest.mark.gpu
+def test_eigen_is_run_to_run_deterministic(eig_path):
+    """Two decompositions of the same matrix must agree bit for bit (no cross-block races, no atomics)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    ctx = bk.Context(0)
+    rng = np.random.default_rng(5)
+    n, p = 3000, 6
+    X = rng.standard_normal((n, p))
+    K = ops.bGaussKernel(ctx.from_numpy(X), float(p))
+    a = ops.bEigen(K, n, 0.0)
+    va, qa = a.values.copy(), a.vectors.to_numpy()
+    ctx.torch.rand((1500, 1500), device=ctx.device)
+    b = ops.bEigen(K, n, 0.0)
+    assert np.array_equal(va, b.values)
+    assert np.array_equal(qa, b.vectors.to_numpy())
