@@ -29,10 +29,21 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int NT = 256;
+#ifndef GEMM_OCC
+#define GEMM_OCC 2
+#endif
 
-template <int W>
-__device__ __forceinline__ int lds_idx(int k, int x) {
-  return k * W + ((((x >> 4) ^ (k & (W / 16 - 1))) << 4) | ((x + k) & 15));
+// LDS layouts of one W x BK operand stage (no swizzle: every index is a per-thread base plus a
+// compile-time constant, so all fragment reads and staging stores use immediate offsets):
+//   contiguous-x operands ("KX"):  [k][x], row stride W + 16 doubles. A half-wave of a fragment
+//       read covers two k rows x 16 x, which land 16 doubles (half the banks) apart.
+//   k-contiguous operands ("XK"):  [x][k], row stride BK + 2 = 18 doubles. A half-wave reads
+//       16 x (18 lm mod 32: the 16 even banks) x 2 k: 32 distinct banks.
+constexpr int LDS_XK = BK + 2;
+constexpr int lds_stage(int w) { return BK * (w + 16); }  // >= w * LDS_XK for w <= 128
+template <bool CONTIG_X, int W>
+__device__ __forceinline__ int lds_at(int k, int x) {
+  return CONTIG_X ? k * (W + 16) + x : x * LDS_XK + k;
 }
 
 // Load a W x 16 operand tile into registers. Element (x, k) lives at
@@ -41,32 +52,65 @@ template <bool CONTIG_X, int W, bool GATHER = false>
 __device__ __forceinline__ void tile_load(const double* __restrict__ src, int64_t ld, int x0,
                                           int k0, int xmax, int kmax, double (&r)[W / 16],
                                           const int* __restrict__ kidx = nullptr) {
+  // Branch-free and select-free: out-of-range elements read a clamped (valid) address.
+  //  * A predicated load puts every load in its own basic block and the compiler then drains
+  //    vmcnt to 0 before the first MFMA of the k-tile; a select right after the load does the
+  //    same. Either way the whole global latency is exposed once per k-tile.
+  //  * Rows/columns past xmax only ever feed accumulator entries that are never stored.
+  //  * k past kmax is zeroed by tile_zero_ktail() just before the LDS store of the last tile.
   const int t = threadIdx.x;
   if (CONTIG_X) {
     const int x = t % W;
     const int kb = t / W;
     constexpr int KS = NT / W;
+    const int gx = x0 + x;
+    const double* base = src + (gx < xmax ? gx : xmax - 1);
 #pragma unroll
     for (int q = 0; q < W / 16; ++q) {
-      const int k = kb + q * KS;
-      const int gx = x0 + x, gk = k0 + k;
-      double v = 0.0;
-      if (gx < xmax && gk < kmax) {
-        const int64_t col = GATHER ? (int64_t)kidx[gk] : (int64_t)gk;
-        v = src[(int64_t)gx + col * ld];
-      }
-      r[q] = v;
+      const int gk = k0 + kb + q * KS;
+      const int kc = gk < kmax ? gk : kmax - 1;
+      const int64_t col = GATHER ? (int64_t)kidx[kc] : (int64_t)kc;
+      r[q] = base[col * ld];
     }
   } else {
     const int k = t & 15;
     const int xb = t >> 4;
+    const int gk = k0 + k;
+    const double* base = src + (gk < kmax ? gk : kmax - 1);
 #pragma unroll
     for (int q = 0; q < W / 16; ++q) {
-      const int x = xb + 16 * q;
-      const int gx = x0 + x, gk = k0 + k;
-      r[q] = (gx < xmax && gk < kmax) ? src[(int64_t)gk + (int64_t)gx * ld] : 0.0;
+      const int gx = x0 + xb + 16 * q;
+      const int xc = gx < xmax ? gx : xmax - 1;
+      r[q] = base[(int64_t)xc * ld];
     }
   }
+}
+
+// zero the staged elements whose k index lies past kmax (last, partial k-tile only)
+template <bool CONTIG_X, int W>
+__device__ __forceinline__ void tile_zero_ktail(int k0, int kmax, double (&r)[W / 16]) {
+  const int t = threadIdx.x;
+  if (CONTIG_X) {
+    const int kb = t / W;
+    constexpr int KS = NT / W;
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q)
+      if (k0 + kb + q * KS >= kmax) r[q] = 0.0;
+  } else {
+    if (k0 + (t & 15) >= kmax) {
+#pragma unroll
+      for (int q = 0; q < W / 16; ++q) r[q] = 0.0;
+    }
+  }
+}
+
+// Fast loader for interior k-tiles: p points at this thread's first element of the tile and
+// the remaining elements follow at a fixed stride, so the address math is one 64-bit add each.
+template <int W>
+__device__ __forceinline__ void tile_load_strided(const double* __restrict__ p, int64_t stride,
+                                                  double (&r)[W / 16]) {
+#pragma unroll
+  for (int q = 0; q < W / 16; ++q) r[q] = p[q * stride];
 }
 
 template <bool CONTIG_X, int W>
@@ -77,12 +121,12 @@ __device__ __forceinline__ void tile_store(double* __restrict__ lds, const doubl
     const int kb = t / W;
     constexpr int KS = NT / W;
 #pragma unroll
-    for (int q = 0; q < W / 16; ++q) lds[lds_idx<W>(kb + q * KS, x)] = r[q];
+    for (int q = 0; q < W / 16; ++q) lds[lds_at<true, W>(kb + q * KS, x)] = r[q];
   } else {
     const int k = t & 15;
     const int xb = t >> 4;
 #pragma unroll
-    for (int q = 0; q < W / 16; ++q) lds[lds_idx<W>(k, xb + 16 * q)] = r[q];
+    for (int q = 0; q < W / 16; ++q) lds[lds_at<false, W>(k, xb + 16 * q)] = r[q];
   }
 }
 
@@ -105,8 +149,10 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
   constexpr bool A_CONTIG = !TA;
   // B tile: op(B)(k,n). transposed: B stored N x K, B[n + k ldb] -> contiguous along n.
   constexpr bool B_CONTIG = TB;
-  double* As[2] = {smem, smem + BK * BM};
-  double* Bs[2] = {smem + 2 * BK * BM, smem + 2 * BK * BM + BK * BN};
+  // LDS stage offsets are kept as integers added to `smem` at each use: selecting between
+  // pointers (double* As[2]) makes the compiler lose the LDS address space and emit flat loads,
+  // whose completion is then tied to the outstanding global loads (vmcnt).
+  constexpr int A_STAGE = lds_stage(BM), B_BASE = 2 * lds_stage(BM), B_STAGE = lds_stage(BN);
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -125,30 +171,66 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
   const int ntiles = (kend - kbeg + BK - 1) / BK;
   if (ntiles <= 0) return;
 
-  tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, kbeg, g.M, kend, ra, g.kidx);
-  tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
-  tile_store<A_CONTIG, BM>(As[0], ra);
-  tile_store<B_CONTIG, BN>(Bs[0], rb);
+  // Per-thread strided pointers for the fast loader (valid for full k-tiles; an operand whose
+  // non-contiguous x range leaves the matrix, or a gathered A, stays on the clamped loader).
+  const int tid = threadIdx.x;
+  const bool a_fast = !GATHER && (A_CONTIG || m0 + BM <= g.M);
+  const bool b_fast = B_CONTIG || n0 + BN <= g.N;
+  const double* pa;
+  const double* pb;
+  int64_t sa, sb, ia, ib;  // element stride inside a tile, pointer advance per k-tile
+  if (A_CONTIG) {
+    const int gx = m0 + tid % BM;
+    pa = g.A + (gx < g.M ? gx : g.M - 1) + (int64_t)(kbeg + tid / BM) * g.lda;
+    sa = (NT / BM) * g.lda;
+    ia = BK * g.lda;
+  } else {
+    pa = g.A + (kbeg + (tid & 15)) + (int64_t)(a_fast ? m0 + (tid >> 4) : 0) * g.lda;
+    sa = 16 * g.lda;
+    ia = BK;
+  }
+  if (B_CONTIG) {
+    const int gx = n0 + tid % BN;
+    pb = g.B + (gx < g.N ? gx : g.N - 1) + (int64_t)(kbeg + tid / BN) * g.ldb;
+    sb = (NT / BN) * g.ldb;
+    ib = BK * g.ldb;
+  } else {
+    pb = g.B + (kbeg + (tid & 15)) + (int64_t)(b_fast ? n0 + (tid >> 4) : 0) * g.ldb;
+    sb = 16 * g.ldb;
+    ib = BK;
+  }
+  auto load_tiles = [&](int k0) {
+    const bool full = k0 + BK <= kend;
+    if (full && a_fast) tile_load_strided<BM>(pa, sa, ra);
+    else tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, k0, g.M, kend, ra, g.kidx);
+    if (full && b_fast) tile_load_strided<BN>(pb, sb, rb);
+    else tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, k0, g.N, kend, rb);
+    pa += ia;
+    pb += ib;
+  };
+
+  load_tiles(kbeg);
+  if (kbeg + BK > kend) {
+    tile_zero_ktail<A_CONTIG, BM>(kbeg, kend, ra);
+    tile_zero_ktail<B_CONTIG, BN>(kbeg, kend, rb);
+  }
+  tile_store<A_CONTIG, BM>(smem, ra);
+  tile_store<B_CONTIG, BN>(smem + B_BASE, rb);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) {
-      const int k0 = kbeg + (t + 1) * BK;
-      tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, k0, g.M, kend, ra, g.kidx);
-      tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, k0, g.N, kend, rb);
-    }
-    const double* as = As[cur];
-    const double* bs = Bs[cur];
-    const int kvalid = kend - (kbeg + t * BK);  // k-steps past the end are all zero: skip them
+    const int k0 = kbeg + (t + 1) * BK;
+    if (t + 1 < ntiles) load_tiles(k0);
+    const double* as = smem + cur * A_STAGE;
+    const double* bs = smem + B_BASE + cur * B_STAGE;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      if (kk >= kvalid) break;
       double af[4], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = as[lds_idx<BM>(kk + lk, wm + i * 16 + lm)];
+      for (int i = 0; i < 4; ++i) af[i] = as[lds_at<A_CONTIG, BM>(kk + lk, wm + i * 16 + lm)];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = bs[lds_idx<BN>(kk + lk, wn + j * 16 + lm)];
+      for (int j = 0; j < NJ; ++j) bf[j] = bs[lds_at<B_CONTIG, BN>(kk + lk, wn + j * 16 + lm)];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -156,8 +238,12 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < ntiles) {
-      tile_store<A_CONTIG, BM>(As[cur ^ 1], ra);
-      tile_store<B_CONTIG, BN>(Bs[cur ^ 1], rb);
+      if (k0 + BK > kend) {  // partial last tile: k rows past the end must contribute zeros
+        tile_zero_ktail<A_CONTIG, BM>(k0, kend, ra);
+        tile_zero_ktail<B_CONTIG, BN>(k0, kend, rb);
+      }
+      tile_store<A_CONTIG, BM>(smem + (cur ^ 1) * A_STAGE, ra);
+      tile_store<B_CONTIG, BN>(smem + B_BASE + (cur ^ 1) * B_STAGE, rb);
     }
     __syncthreads();
   }
@@ -185,7 +271,7 @@ __device__ __forceinline__ void acc_foreach(const d4 (&acc)[4][BN / 32], int m0,
       }
 }
 
-constexpr size_t smem_bytes(int bn) { return (size_t)(2 * BK * BM + 2 * BK * bn) * sizeof(double); }
+constexpr size_t smem_bytes(int bn) { return (size_t)(2 * lds_stage(BM) + 2 * lds_stage(bn)) * sizeof(double); }
 
 // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give
 // each XCD a contiguous run of tiles (neighbouring tiles share operand panels in
@@ -203,7 +289,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // plain GEMM kernels
 // ---------------------------------------------------------------------------
 template <bool TA, bool TB, int BN>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmOperands g, double alpha, double beta,
+__global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, double alpha, double beta,
                                                   double* __restrict__ C, int64_t ldc,
                                                   int tiles_m, int tiles_n, int k_chunk,
                                                   double* __restrict__ partial) {
@@ -235,26 +321,27 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmOperands g, double alpha, 
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
       const int lm = lane & 15, lk = lane >> 4;
-      d4 cold[4][NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j) {
+        // one 64 x 16 column strip at a time: 16 loads in flight per lane, then 16 stores (the
+        // second workgroup of the CU covers the latency; a full-tile batch would spill)
+        d4 cold[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
-            cold[i][j][r] = (m < M && n < N) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
+            cold[i][r] = (m < M && n < N) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
           }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
             if (m < M && n < N)
-              C[(int64_t)m + (int64_t)n * ldc] = alpha * acc[i][j][r] + beta * cold[i][j][r];
+              C[(int64_t)m + (int64_t)n * ldc] = alpha * acc[i][j][r] + beta * cold[i][r];
           }
+      }
     }
   }
 }
@@ -365,7 +452,7 @@ int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, doub
 //  A22 -= [V W][W V]', whose consumers only ever read the lower triangle).
 // Only tiles with tile_row >= tile_col are launched.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void syrk_lower_kernel(GemmOperands g, double alpha,
+__global__ __launch_bounds__(NT, GEMM_OCC) void syrk_lower_kernel(GemmOperands g, double alpha,
                                                         double* __restrict__ C, int64_t ldc,
                                                         int tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -392,7 +479,7 @@ __global__ __launch_bounds__(NT) void syrk_lower_kernel(GemmOperands g, double a
 // triangle (through a per-wave 16 x 16 LDS transpose so that the mirrored stores are 128-byte
 // segments too): C stays a fully stored, exactly symmetric matrix at half the MFMA work of a
 // full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
-__global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double alpha,
+__global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands g, double alpha,
                                                          double* __restrict__ C, int64_t ldc,
                                                          int tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -410,22 +497,20 @@ __global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double 
   const int lm = lane & 15, lk = lane >> 4;
   double* buf = smem + wave * (16 * 17);
   const bool diag_tile = (tm == tn);
-  // All 64 C values of this lane are fetched in one batch (one exposed memory latency instead
-  // of sixteen: with one workgroup per CU nothing else would hide them).
-  d4 cold[4][4];
+  // C is fetched one 64 x 16 column strip at a time (16 loads in flight per lane); the other
+  // workgroup resident on the CU covers the latency.
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    d4 cold[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm + i * 16 + lm;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn + j * 16 + lk + 4 * r;
-        cold[i][j][r] = (m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
+        cold[i][r] = (m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
       }
     }
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mt0 = m0 + wm + i * 16, nt0 = n0 + wn + j * 16;  // 16 x 16 sub-tile origin
@@ -438,7 +523,7 @@ __global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double 
         double v = 0.0;
         if (m < M && n < M && m >= n) {
           const int64_t o = (int64_t)m + (int64_t)n * ldc;
-          v = cold[i][j][r] + alpha * acc[i][j][r];
+          v = cold[i][r] + alpha * acc[i][j][r];
           C[o] = v;
         }
         vals[r] = v;
@@ -452,6 +537,7 @@ __global__ __launch_bounds__(NT) void syrk_mirror_kernel(GemmOperands g, double 
         if (mm < M && nn < M && mm > nn) C[(int64_t)nn + (int64_t)mm * ldc] = v;
       }
     }
+  }
 }
 
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
@@ -495,7 +581,7 @@ int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doubl
 // ---------------------------------------------------------------------------
 // batched NN GEMM (divide & conquer merges): one descriptor per problem
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void gemm_batched_nn_kernel(const GemmDesc* __restrict__ descs,
+__global__ __launch_bounds__(NT, GEMM_OCC) void gemm_batched_nn_kernel(const GemmDesc* __restrict__ descs,
                                                              int tiles_m_max) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const GemmDesc d = descs[blockIdx.y];
