@@ -321,11 +321,10 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, doub
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
       const int lm = lane & 15, lk = lane >> 4;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        // one 64 x 16 column strip at a time: 16 loads in flight per lane, then 16 stores (the
-        // second workgroup of the CU covers the latency; a full-tile batch would spill)
-        d4 cold[4];
+      // one 64 x 16 column strip at a time, software pipelined: the loads of strip j+1 are
+      // issued before the stores of strip j (vmcnt is in-order over loads and stores, so loads
+      // issued after a strip's stores would also wait for those stores to retire)
+      auto load_strip = [&](int j, d4 (&cold)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -333,13 +332,19 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, doub
             const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
             cold[i][r] = (m < M && n < N) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
           }
+      };
+      d4 cold[2][4];
+      load_strip(0, cold[0]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (j + 1 < NJ) load_strip(j + 1, cold[(j + 1) & 1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm + i * 16 + lm, n = n0 + wn + j * 16 + lk + 4 * r;
             if (m < M && n < N)
-              C[(int64_t)m + (int64_t)n * ldc] = alpha * acc[i][j][r] + beta * cold[i][r];
+              C[(int64_t)m + (int64_t)n * ldc] = alpha * acc[i][j][r] + beta * cold[j & 1][i][r];
           }
       }
     }
@@ -497,11 +502,9 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
   const int lm = lane & 15, lk = lane >> 4;
   double* buf = smem + wave * (16 * 17);
   const bool diag_tile = (tm == tn);
-  // C is fetched one 64 x 16 column strip at a time (16 loads in flight per lane); the other
-  // workgroup resident on the CU covers the latency.
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    d4 cold[4];
+  // C is fetched one 64 x 16 column strip at a time, one strip ahead of the stores (vmcnt is
+  // in-order over loads and stores: loads issued after a strip's stores would wait for them).
+  auto load_strip = [&](int j, d4 (&cold)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm + i * 16 + lm;
@@ -511,6 +514,13 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
         cold[i][r] = (m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
       }
     }
+  };
+  d4 coldbuf[2][4];
+  load_strip(0, coldbuf[0]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j + 1 < 4) load_strip(j + 1, coldbuf[(j + 1) & 1]);
+    d4 (&cold)[4] = coldbuf[j & 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mt0 = m0 + wm + i * 16, nt0 = n0 + wn + j * 16;  // 16 x 16 sub-tile origin
