@@ -57,6 +57,19 @@ int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out) {
   return BIGKRLS_OK;
 }
 
+int side_stream_get(bigkrls_ctx* ctx) {
+  if (!ctx->side_stream) {
+    // highest priority: its short latency-bound launches must not queue behind the thousands of
+    // workgroups of the throughput kernel they overlap with
+    int prio_lo = 0, prio_hi = 0;
+    BK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    BK_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
+    BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  return BIGKRLS_OK;
+}
+
 static bigkrls_ctx::ProfEntry* prof_entry(bigkrls_ctx* ctx, const char* name) {
   for (auto& e : ctx->prof)
     if (e.name == name) return &e;
@@ -226,6 +239,9 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)bigkrls_ctx_release_workspace(ctx);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return BIGKRLS_OK;

@@ -45,6 +45,10 @@ struct bigkrls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  // side stream + events for look-ahead inside the eigensolver (panel QR of the next block
+  // column runs concurrently with the rest of the trailing update); created on first use
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
   static constexpr int kSlots = 32;
   void* ws[kSlots] = {nullptr};
@@ -105,8 +109,11 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                const double* B, int64_t ldb, double* C, int64_t ldc);
 
+// tile columns [tn_begin, tn_end) of the lower tile triangle only (tn_end < 0: all of them)
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
-                const double* B, int64_t ldb, double* C, int64_t ldc);
+                const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin = 0,
+                int tn_end = -1);
+int side_stream_get(bigkrls_ctx* ctx);
 
 // batched GEMM for the divide & conquer merges: per-problem descriptors on device
 struct GemmDesc {

@@ -486,9 +486,9 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_lower_kernel(GemmOperands g
 // full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
 __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands g, double alpha,
                                                          double* __restrict__ C, int64_t ldc,
-                                                         int tiles) {
+                                                         int tiles, int t_off) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int t = blockIdx.x;
+  const int t = blockIdx.x + t_off;
   int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t)) * 0.5);
   while (tn > 0 && tn * tiles - tn * (tn - 1) / 2 > t) --tn;
   while ((tn + 1) * tiles - (tn + 1) * tn / 2 <= t) ++tn;
@@ -551,12 +551,16 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
 }
 
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
-                const double* B, int64_t ldb, double* C, int64_t ldc) {
+                const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin, int tn_end) {
   if (m <= 0 || k <= 0) return BIGKRLS_OK;
   BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror: dimension too large");
   GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
   const int tiles = (int)((m + BM - 1) / BM);
-  const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
+  if (tn_end < 0 || tn_end > tiles) tn_end = tiles;
+  if (tn_begin >= tn_end) return BIGKRLS_OK;
+  // lower-triangular tiles are enumerated column by column: column c starts at c*tiles - c(c-1)/2
+  auto first_of = [&](int64_t c) { return c * tiles - c * (c - 1) / 2; };
+  const int64_t t0 = first_of(tn_begin), nt = first_of(tn_end) - t0;
   static bool attr_set = false;
   if (!attr_set) {
     BK_HIP(hipFuncSetAttribute((const void*)syrk_mirror_kernel,
@@ -564,7 +568,7 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
     attr_set = true;
   }
   hipLaunchKernelGGL(syrk_mirror_kernel, dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
-                     alpha, C, ldc, tiles);
+                     alpha, C, ldc, tiles, (int)t0);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
 }
