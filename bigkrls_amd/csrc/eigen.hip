@@ -1203,8 +1203,18 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     int blocks = (int)std::min<int64_t>(((int64_t)S2_LD * N + 255) / 256, 8192);
     hipLaunchKernelGGL(s1_extract_band, dim3(blocks), dim3(256), 0, st, (const double*)W, n, AB);
     BK_CHECK_LAUNCH();
-    BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e));
+    // progress flags / error word of the persistent bulge-chasing kernel: the (unused here)
+    // tau and scratch vectors of the one-stage path
+    int* bc_err = (int*)scratch;
+    BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
+    int h_err = 0;
+    BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
+    if (h_err != 0) {
+      set_error("eigen: bulge-chasing watchdog fired (workgroups of the persistent kernel were not "
+                "co-resident); rerun with BIGKRLS_BC=wavefront");
+      return BIGKRLS_EHIP;
+    }
   } else if (n >= 2) {
     BK_TRY(tridiagonalize(ctx, W, n, d, e, tau, P1, P2, scratch, sw));
   } else {
