@@ -1071,33 +1071,36 @@ __global__ void bt_extract_panel(const double* __restrict__ W, int n, int j0, in
 }
 
 // T (pw x pw upper triangular) from G = Vp'Vp and tau (LAPACK dlarft, forward/columnwise)
-__global__ __launch_bounds__(64) void bt_build_t(const double* __restrict__ G, int pw,
-                                                 const double* __restrict__ tau,
-                                                 double* __restrict__ T) {
-  __shared__ double sT[TRD_NB * TRD_NB];
+__global__ __launch_bounds__(256) void bt_build_t(const double* __restrict__ G, int pw,
+                                                  const double* __restrict__ tau,
+                                                  double* __restrict__ T) {
+  // column i of T needs columns 0..i-1: pw dependent steps; inside a step row r of the
+  // triangular product is shared by 4 lanes (k strided by 4) and folded with two shuffles
+  __shared__ double sT[TRD_NB * (TRD_NB + 1)];   // row-major with a padded stride: sT[r][k]
   __shared__ double sG[TRD_NB * TRD_NB];
   __shared__ double stau[TRD_NB];
+  constexpr int LT = TRD_NB + 1;
   const int t = threadIdx.x;
-  for (int e = t; e < pw * pw; e += 64) {
-    sT[e] = 0.0;
-    sG[e] = G[e];   // one batch of global loads instead of a dependent load per inner step
-  }
+  for (int e = t; e < TRD_NB * LT; e += 256) sT[e] = 0.0;
+  for (int e = t; e < pw * pw; e += 256) sG[e] = G[e];   // one batch of global loads
   if (t < pw) stau[t] = tau[t];
   __syncthreads();
+  const int r = t >> 2, part = t & 3;
   for (int i = 0; i < pw; ++i) {
     const double ti = stau[i];
-    // T[0:i, i] = -tau_i * T[0:i,0:i] * G[0:i, i]
+    // T[0:i, i] = -tau_i * T[0:i,0:i] * G[0:i, i]   (row r only has entries k >= r)
     double acc = 0.0;
-    if (t < i) {
-      for (int k = t; k < i; ++k) acc += sT[t + k * pw] * sG[k + i * pw];  // upper triangular rows
-      acc *= -ti;
+    if (r < i)
+      for (int k = r + part; k < i; k += 4) acc += sT[r * LT + k] * sG[k + i * pw];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) {
+      if (r < i) sT[r * LT + i] = -ti * acc;
+      else if (r == i) sT[i * LT + i] = ti;
     }
     __syncthreads();
-    if (t < i) sT[t + i * pw] = acc;
-    if (t == i) sT[i + i * pw] = ti;
-    __syncthreads();
   }
-  for (int e = t; e < pw * pw; e += 64) T[e] = sT[e];
+  for (int e = t; e < pw * pw; e += 256) T[e] = sT[(e % pw) * LT + (e / pw)];
 }
 
 int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, double* Z,
@@ -1122,7 +1125,7 @@ int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, 
     hipLaunchKernelGGL(bt_extract_panel, dim3(blocks), dim3(256), 0, st, W, n, j0, pw, Vp, ne);
     BK_CHECK_LAUNCH();
     BK_TRY(gemm(ctx, 1, 0, pw, pw, ne, 1.0, Vp, ne, Vp, ne, 0.0, G, pw));
-    hipLaunchKernelGGL(bt_build_t, dim3(1), dim3(64), 0, st, (const double*)G, pw, tau + j0, T);
+    hipLaunchKernelGGL(bt_build_t, dim3(1), dim3(256), 0, st, (const double*)G, pw, tau + j0, T);
     BK_CHECK_LAUNCH();
     double* Zs = Z + (j0 + 1);
     BK_TRY(gemm(ctx, 1, 0, pw, nv, ne, 1.0, Vp, ne, Zs, ldz, 0.0, W1, pw));
