@@ -1178,7 +1178,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int64_t nb64 = N * S2_B;
     void *p2 = nullptr, *pvv = nullptr;
     const int64_t maxb = (N + 255) / 256 + 2;
-    const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N;
+    const int64_t nmail = 2 * maxb * 2 * S2_B;   // pq_resident: 2 buffers x workgroups x 64 word pairs
+    const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N + nmail;
     const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
     const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
@@ -1191,6 +1192,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     s1.PZ2 = q; q += 2 * nb64;
     s1.small = q; q += 8 * S2_B * S2_B;
     s1.part = q; q += npart;
+    s1.mail = s1.part + (npart - nmail);
+    s1.err = (int*)scratch;
+    BK_HIP(hipMemsetAsync(s1.mail, 0, nmail * sizeof(double), st));
+    BK_HIP(hipMemsetAsync(s1.err, 0, sizeof(int), st));
     s1.Tall = q; q += ntall;
     taus1 = q; q += 2 * N;
     AB = q; q += (int64_t)S2_LD * N;
@@ -1214,8 +1219,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
     if (h_err != 0) {
-      set_error("eigen: bulge-chasing watchdog fired (workgroups of the persistent kernel were not "
-                "co-resident); rerun with BIGKRLS_BC=wavefront");
+      set_error("eigen: watchdog of a persistent kernel fired (its workgroups were not co-resident); "
+                "rerun with BIGKRLS_PQ=steps BIGKRLS_BC=wavefront");
       return BIGKRLS_EHIP;
     }
   } else if (n >= 2) {
