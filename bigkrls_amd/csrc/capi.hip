@@ -78,27 +78,28 @@ static bigkrls_ctx::ProfEntry* prof_entry(bigkrls_ctx* ctx, const char* name) {
   return &ctx->prof.back();
 }
 
-int prof_begin(bigkrls_ctx* ctx, const char* name, double work) {
+int prof_begin(bigkrls_ctx* ctx, const char* name, double work, hipStream_t stream) {
   if (!ctx->profile) return BIGKRLS_OK;
   bigkrls_ctx::ProfSample s{};
   BK_HIP(hipEventCreate(&s.e0));
   BK_HIP(hipEventCreate(&s.e1));
   s.work = work;
-  BK_HIP(hipEventRecord(s.e0, ctx->stream));
+  BK_HIP(hipEventRecord(s.e0, stream ? stream : ctx->stream));
   prof_entry(ctx, name)->pending.push_back(s);
   return BIGKRLS_OK;
 }
 
-int prof_end(bigkrls_ctx* ctx, const char* name) {
+int prof_end(bigkrls_ctx* ctx, const char* name, hipStream_t stream) {
   if (!ctx->profile) return BIGKRLS_OK;
   auto* e = prof_entry(ctx, name);
   if (e->pending.empty()) return BIGKRLS_OK;
-  BK_HIP(hipEventRecord(e->pending.back().e1, ctx->stream));
+  BK_HIP(hipEventRecord(e->pending.back().e1, stream ? stream : ctx->stream));
   return BIGKRLS_OK;
 }
 
 static int prof_flush(bigkrls_ctx* ctx) {
   BK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->side_stream) BK_HIP(hipStreamSynchronize(ctx->side_stream));
   for (auto& e : ctx->prof) {
     for (auto& s : e.pending) {
       float ms = 0.f;

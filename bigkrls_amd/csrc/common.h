@@ -94,8 +94,8 @@ enum Slot {
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
 // Bracket one launch with HIP events when ctx->profile is on: call prof_begin before the
 // launch and prof_end after it; `work` is the launch's algorithmic bytes (or flops).
-int prof_begin(bigkrls_ctx* ctx, const char* name, double work);
-int prof_end(bigkrls_ctx* ctx, const char* name);
+int prof_begin(bigkrls_ctx* ctx, const char* name, double work, hipStream_t stream = nullptr);
+int prof_end(bigkrls_ctx* ctx, const char* name, hipStream_t stream = nullptr);
 int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out);
 
 // ---- gemm.hip -----------------------------------------------------------------

@@ -488,6 +488,14 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
                                                          double* __restrict__ C, int64_t ldc,
                                                          int tiles, int t_off) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // De-phase the workgroups that share a CU: with identical tiles they would run their MFMA
+  // loops and their (memory-bound) epilogues in lockstep and never overlap one with the other.
+  // Only the first resident generation needs it; later workgroups inherit the phase of the
+  // slot they replace.
+  if (blockIdx.x < 1024) {
+    const unsigned h = (blockIdx.x * 2654435761u) >> 29;   // 0..7
+    for (unsigned q = 0; q < h; ++q) __builtin_amdgcn_s_sleep(127);   // 8128 cycles ~ 3.4 us each
+  }
   const int t = blockIdx.x + t_off;
   int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t)) * 0.5);
   while (tn > 0 && tn * tiles - tn * (tn - 1) / 2 > t) --tn;

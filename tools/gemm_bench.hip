@@ -26,6 +26,9 @@ int main(int argc, char** argv) {
     printf("%-44s %9.1f us  %7.2f TFLOP/s\n", name, ms * 1e3, flops / (ms * 1e-3) / 1e12);
   };
   timeit("syrk_mirror m=n k=128", (double)n * (n + 1) * 128, [&] { syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n); });
+  timeit("syrk_mirror m=n k=16 (epilogue only)", (double)n * (n + 1) * 16, [&] { syrk_mirror(ctx, n, 16, -1.0, A, n, B, n, C, n); });
+  timeit("gemm NT k=16 beta=1 (epilogue only)", 2.0 * n * n * 16, [&] { gemm(ctx, 0, 1, n, n, 16, -1.0, A, n, B, n, 1.0, C, n); });
+  timeit("gemm NT k=16 beta=0 (epilogue only)", 2.0 * n * n * 16, [&] { gemm(ctx, 0, 1, n, n, 16, -1.0, A, n, B, n, 0.0, C, n); });
   timeit("syrk_lower  m=n k=128", (double)n * (n + 1) * 128, [&] { syrk_lower(ctx, n, 128, -1.0, A, n, B, n, C, n); });
   timeit("gemm NT m=n=n k=128 beta=1", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 1.0, C, n); });
   timeit("gemm NT m=n=n k=128 beta=0", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 0.0, C, n); });
