@@ -11,9 +11,11 @@ DESIGN.md).  Rank 0 prints ONE JSON line.  For N > 1 the same fit is row-block
 partitioned over the ranks (strong scaling): see bigkrls_amd/dist.py.
 
 `roofline` is for the dominant kernel of the fit -- whichever of the profiled
-eigensolver kernels (bulge chasing, the stage-1 band update / A22 V GEMMs, or the
-one-stage symv) takes the most time -- measured live with HIP events on the
-launch stream; `kernel_gemm` reports the Gaussian-kernel GEMM the metric names.
+eigensolver kernels (the stage-1 band update / A22 V GEMMs, bulge chasing, or the
+one-stage symv) takes the most time on the critical path -- measured live with HIP
+events on the launch stream; the panel QR, which runs concurrently on the look-ahead
+stream, is listed in `other_kernels`; `kernel_gemm` reports the Gaussian-kernel GEMM
+the metric names.
 `cpu_baseline` times the oracle's literal restatement of the reference on the
 host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -219,7 +221,7 @@ def main():
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
-                    "total_ms_per_fit": round(ms / args.steps, 2),
+                    "total_ms_per_fit": round(ms / args.steps, 2), "concurrent": True,
                     "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
                     "note": "achieved = algorithmic bytes (panel read + written once, V written once: 24 m b) / "
                             "HIP-event duration on the look-ahead stream. The kernel is bound by 64 dependent "
@@ -238,7 +240,11 @@ def main():
                        "achieved = 2 m^2 b flops per launch / HIP-event duration"),
         ]
         cands = [c for c in cands if c]
-        roof = max(cands, key=lambda c: c["total_ms_per_fit"]) if cands else None
+        # The dominant kernel is the one with the most time on the critical path: pq_resident runs on
+        # the look-ahead stream concurrently with (and hidden behind) syrk_mirror_kernel, so its kernel
+        # time -- the largest in a rocprofv3 listing -- is not wall time; it is reported in other_kernels.
+        crit = [c for c in cands if not c.get("concurrent")]
+        roof = max(crit or cands, key=lambda c: c["total_ms_per_fit"]) if cands else None
         tu_ms, tu_flops, tu_n = prof["trailing_update"]
         res = {
             "metric": "bigKRLS_fit_wall_clock_s (full fit, N=20000, P=20, fp64)" if (n, p) == (20000, 20)
