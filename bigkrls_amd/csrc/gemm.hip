@@ -818,6 +818,144 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
     }
 }
 
+// Paired 16-byte stores of one wave's 32 x 32 tile held in MFMA accumulator layout
+// (e[i][j][r] = element (m0 + 16 i + (lane & 15), n0 + 16 j + (lane >> 4) + 4 r)): adjacent lanes
+// (rows 2t, 2t+1) swap one value so that the even lane owns rows (2t, 2t+1) of column n(r) and the
+// odd lane the same rows of column n(r+1).
+__device__ __forceinline__ void kb_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
+                                              int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int lm = lane & 15, lk = lane >> 4;
+  const bool odd = (lane & 1) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + lm;
+        if (vec_ok) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          const double lo = odd ? recv : e[i][j][rp];
+          const double hi = odd ? e[i][j][rp + 1] : recv;
+          const int mrow = m & ~1;                              // first of the row pair
+          const int n = n0 + j * 16 + lk + 4 * (rp + (odd ? 1 : 0));
+          if (n < V) {
+            double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
+            if (mrow + 1 < U) *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
+            else if (mrow < U) dst[0] = lo;
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int n = n0 + j * 16 + lk + 4 * (rp + rr);
+            if (m < U && n < V) out[(int64_t)m + (int64_t)n * ldo] = e[i][j][rp + rr];
+          }
+        }
+      }
+}
+
+// Symmetric Gram variant (A == B, square, unit diagonal): only the wave tiles on or below the
+// diagonal are computed (half the MFMA, exp and operand traffic); an off-diagonal tile is stored
+// twice, the second time transposed through a wave-private LDS buffer so that the mirrored
+// stores are the same 16-byte row pairs.
+template <int KS>
+__global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
+    const double* __restrict__ A, int64_t lda, int U, int P, const double* __restrict__ na,
+    double neg_inv_sigma, double* __restrict__ out, int64_t ldo, int tiles, int64_t ntiles) {
+  __shared__ double tbuf[4][32 * 33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  if (w >= ntiles) return;
+  // lower-triangular tiles column by column: column c starts at c*tiles - c(c-1)/2
+  int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * (double)w)) * 0.5);
+  while (tn > 0 && (int64_t)tn * tiles - (int64_t)tn * (tn - 1) / 2 > w) --tn;
+  while ((int64_t)(tn + 1) * tiles - (int64_t)(tn + 1) * tn / 2 <= w) ++tn;
+  const int tm = tn + (int)(w - ((int64_t)tn * tiles - (int64_t)tn * (tn - 1) / 2));
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int ma0 = min(m0 + lm, U - 1), ma1 = min(m0 + 16 + lm, U - 1);
+  const int nb0 = min(n0 + lm, U - 1), nb1 = min(n0 + 16 + lm, U - 1);
+  const double* a0p = A + ma0;
+  const double* a1p = A + ma1;
+  const double* b0p = A + nb0;
+  const double* b1p = A + nb1;
+  double nbv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nbv[j][r] = na[min(n0 + j * 16 + lk + 4 * r, U - 1)];
+  double nam[2];
+  nam[0] = na[ma0];
+  nam[1] = na[ma1];
+  for (int kc0 = 0; kc0 < P; kc0 += 4 * KS) {
+    double fa0[KS], fa1[KS], fb0[KS], fb1[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = kc0 + 4 * s + lk;
+      const int64_t kc = min(k, P - 1);
+      fa0[s] = a0p[kc * lda];
+      fa1[s] = a1p[kc * lda];
+      fb0[s] = b0p[kc * lda];
+      fb1[s] = b1p[kc * lda];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bool kv = (kc0 + 4 * s + lk) < P;
+      const double a0 = kv ? fa0[s] : 0.0, a1 = kv ? fa1[s] : 0.0;
+      const double b0 = kv ? fb0[s] : 0.0, b1 = kv ? fb1[s] : 0.0;
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+    }
+  }
+  const bool vec_ok = ((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool diag_tile = (tm == tn);
+  double e[2][2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + j * 16 + lk + 4 * r;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + lm;
+        double d2 = fma(-2.0, acc[i][j][r], nam[i] + nbv[j][r]);
+        d2 = fmax(d2, 0.0);
+        double v = exp_nonpos(d2 * neg_inv_sigma);
+        if (diag_tile && m == n) v = 1.0;
+        e[i][j][r] = v;
+      }
+    }
+  kb_store_tile(out, ldo, U, U, m0, n0, e, vec_ok);
+  if (!diag_tile) {
+    // transpose through LDS: E[mloc][nloc], then the mirrored tile's accumulator layout reads
+    // element (m' = n0 + 16 i + lm, n' = m0 + 16 j + lk + 4 r) = E[16 j + lk + 4 r][16 i + lm]
+    double* tb = tbuf[wave];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(i * 16 + lm) * 33 + (j * 16 + lk + 4 * r)] = e[i][j][r];
+    double et[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) et[i][j][r] = tb[(j * 16 + lk + 4 * r) * 33 + (i * 16 + lm)];
+    kb_store_tile(out, ldo, U, U, n0, m0, et, vec_ok);
+  }
+}
+
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift) {
@@ -831,6 +969,34 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   BK_TRY(ws_get(ctx, SLOT_NORMS_B, v * sizeof(double), &pnb));
   BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
   BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
+  if (p <= 128 && A == B && u == v && lda == ldb && diag_shift == 0) {
+    // symmetric Gram matrix (bGaussKernel): lower wave tiles + mirrored stores
+    const int tiles = (int)((u + 31) / 32);
+    const int64_t ntiles = (int64_t)tiles * (tiles + 1) / 2;
+    BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
+    const int steps = (int)((p + 3) / 4);
+    const int chunks = (steps + 7) / 8;
+    const int ks = (steps + chunks - 1) / chunks;
+    BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
+    const dim3 grid((unsigned)((ntiles + 3) / 4));
+#define BK_KBS(KS)                                                                                 \
+  hipLaunchKernelGGL(kernel_block_sym_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u,   \
+                     (int)p, (const double*)pna, -1.0 / sigma, out, ldo, tiles, ntiles)
+    switch (ks) {
+      case 1: BK_KBS(1); break;
+      case 2: BK_KBS(2); break;
+      case 3: BK_KBS(3); break;
+      case 4: BK_KBS(4); break;
+      case 5: BK_KBS(5); break;
+      case 6: BK_KBS(6); break;
+      case 7: BK_KBS(7); break;
+      default: BK_KBS(8); break;
+    }
+#undef BK_KBS
+    BK_CHECK_LAUNCH();
+    BK_TRY(prof_end(ctx, "kernel_block"));
+    return BIGKRLS_OK;
+  }
   if (p <= 128) {
     const int tiles_m = (int)((u + 31) / 32), tiles_n = (int)((v + 31) / 32);
     const int64_t ntiles = (int64_t)tiles_m * tiles_n;
