@@ -249,3 +249,29 @@ def test_eigen_is_run_to_run_deterministic(eig_path):
     b = ops.bEigen(K, n, 0.0)
     assert np.array_equal(va, b.values)
     assert np.array_equal(qa, b.vectors.to_numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bc,pq", [("wavefront", "steps"), ("persistent", "steps"), ("resident", "resident")])
+@pytest.mark.parametrize("n", [513, 1283])
+def test_eigen_two_stage_kernel_variants(lib, monkeypatch, bc, pq, n):
+    """The fallback kernels of the two-stage path (one launch per bulge-chasing wavefront / per panel
+    column, and the flag-synchronised persistent bulge chasing) must stay correct: they serve the
+    sizes the LDS- and register-resident kernels cannot (n > 32768, panels of > 80 workgroups)."""
+    monkeypatch.delenv("BIGKRLS_EIG", raising=False)
+    monkeypatch.setenv("BIGKRLS_BC", bc)
+    if pq == "steps":
+        monkeypatch.setenv("BIGKRLS_PQ", "steps")
+    else:
+        monkeypatch.delenv("BIGKRLS_PQ", raising=False)
+    X, y = orc.synth(n, 5, 21)
+    K = orc.gauss_kernel_literal(X, 5.0)
+    vals = np.zeros(n)
+    vecs = F(np.zeros((n, n)))
+    Kf = F(K)
+    check(lib, lib.bigkrls_eigen(P(Kf), n, n, P(vals), P(vecs)))
+    ref_vals, _ = orc.big_eigen_literal(K, n)
+    scale = np.abs(ref_vals).max()
+    assert np.max(np.abs(vals - ref_vals)) / scale < 1e-12
+    assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-11
+    assert np.max(np.abs(K @ vecs - vecs * vals)) / scale < 1e-11
