@@ -40,10 +40,15 @@ constexpr int NT = 256;
 //   k-contiguous operands ("XK"):  [x][k], row stride BK + 2 = 18 doubles. A half-wave reads
 //       16 x (18 lm mod 32: the 16 even banks) x 2 k: 32 distinct banks.
 constexpr int LDS_XK = BK + 2;
-constexpr int lds_stage(int w) { return BK * (w + 16); }  // >= w * LDS_XK for w <= 128
+#ifndef GEMM_KX_PAD
+#define GEMM_KX_PAD 16
+#endif
+constexpr int lds_stage(int w) {   // room for either layout
+  return BK * (w + GEMM_KX_PAD) > w * LDS_XK ? BK * (w + GEMM_KX_PAD) : w * LDS_XK;
+}
 template <bool CONTIG_X, int W>
 __device__ __forceinline__ int lds_at(int k, int x) {
-  return CONTIG_X ? k * (W + 16) + x : x * LDS_XK + k;
+  return CONTIG_X ? k * (W + GEMM_KX_PAD) + x : x * LDS_XK + k;
 }
 
 // Load a W x 16 operand tile into registers. Element (x, k) lives at
