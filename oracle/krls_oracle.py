@@ -6,14 +6,20 @@ checker for the HIP path and the `cpu_baseline` leg of bench.py.  Nothing under
 `bigkrls_amd/` may import it.  Only `tests/`, `__graft_entry__.smoke()` and
 bench.py's `cpu_baseline` leg do.
 
-Pinning status: the reference's own tests pin only (i) one kernel column of
-`mtcars` (tests/testthat/test_basic_usage.R:71-108, one-sided tol 0.01) and (ii)
-one predicted proportion, 0.6875 (:64-67).  Both are checked in
-tests/test_oracle_golden.py against this file.  Eigenvalues, lambda, coefficients
-and derivatives are **parity unpinned** by the reference's tests; the informal
-known-answer material in examples/numeric_convergence.md needs R's RNG stream and
-cannot be regenerated without R.  The reference cannot be built here (no R, Rcpp,
-RcppArmadillo, bigmemory) so there is no `oracle/_ref`.
+Pinning status (all checked in tests/test_oracle.py against this file):
+(i) the reference's own tests pin one kernel column of `mtcars`
+(tests/testthat/test_basic_usage.R:71-108, one-sided tol 0.01) and (ii) one predicted
+proportion, 0.6875 (:64-67): reproduced to 7e-15 and exactly; (iii) the reference's
+only end-to-end known answer -- the six average marginal effects of the N=500, P=6
+(binary last column), eigtrunc=0.01 fit printed in examples/numeric_convergence.md:40-46
+-- is reproduced to all 7 printed significant figures by both the literal and the
+O(N^2) restatement, from inputs regenerated with a restatement of R's random stream
+(oracle/r_rng.py: set.seed scrambling, Mersenne-Twister, inversion rnorm, itself
+checked against R's well-known first draws). (iii) pins kernel -> eigen -> truncation
+-> lambda search -> coefficients -> continuous and binary derivatives -> rescaling.
+Individual eigenvalues, lambda and c are not printed anywhere in the reference tree.
+The reference cannot be built here (no R, Rcpp, RcppArmadillo, bigmemory) so there is
+no `oracle/_ref`.
 
 Where the arithmetic lives in third-party code that is absent from
 /root/reference (Armadillo via RcppArmadillo -> LAPACK dsyevd / BLAS dgemm;

@@ -15,7 +15,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("name,kw", [("c1_n500_p5.npz", {}), ("n500_p6_binary_trunc01.npz", {"eigtrunc": 0.01}),
-                                     ("n32_p4.npz", {})])
+                                     ("numeric_convergence_n500_p6.npz", {"eigtrunc": 0.01}), ("n32_p4.npz", {})])
 def test_fit_matches_committed_golden(ctx, name, kw):
     import bigkrls_amd as bk
     g = np.load(os.path.join(HERE, "golden", name))
@@ -30,6 +30,11 @@ def test_fit_matches_committed_golden(ctx, name, kw):
     assert rel(K[0], g["K_row0"]) < 1e-12
     assert rel(np.diag(np.asarray(out["vcov.est.c"])), g["vcov_c_diag"]) < 1e-6
     assert rel(np.diag(np.asarray(out["vcov.est.fitted"])), g["vcov_fitted_diag"]) < 1e-6
+    if "reference_avgderivatives" in g.files:
+        # the reference's own published numbers (examples/numeric_convergence.md:40-46), 7 s.f.
+        ref = g["reference_avgderivatives"]
+        got = np.asarray(out["avgderivatives"]).ravel()
+        assert np.all(np.abs(got - ref) <= 5.1e-7 * np.abs(ref)), (got, ref)
     if "pred" in g.files:
         pr = bk.predict(out, g["X"][:8] + 0.1, se_pred=True)
         assert rel(pr["predicted"], g["pred"]) < 1e-6 and rel(pr["se.pred"], g["se_pred"]) < 1e-6
