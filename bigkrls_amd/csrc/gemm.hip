@@ -35,13 +35,15 @@ constexpr int NT = 256;
 
 // LDS layouts of one W x BK operand stage (no swizzle: every index is a per-thread base plus a
 // compile-time constant, so all fragment reads and staging stores use immediate offsets):
-//   contiguous-x operands ("KX"):  [k][x], row stride W + 16 doubles. A half-wave of a fragment
-//       read covers two k rows x 16 x, which land 16 doubles (half the banks) apart.
+//   contiguous-x operands ("KX"):  [k][x], row stride W + GEMM_KX_PAD doubles. A half-wave of a
+//       fragment read covers two k rows x 16 x; with a pad of 16 they land half the banks apart
+//       (conflict-free), with 8 half of the lanes pay a 2-way conflict -- not measurable, and the
+//       128 x 64 tile then needs 52 KB, so three workgroups fit a CU.
 //   k-contiguous operands ("XK"):  [x][k], row stride BK + 2 = 18 doubles. A half-wave reads
 //       16 x (18 lm mod 32: the 16 even banks) x 2 k: 32 distinct banks.
 constexpr int LDS_XK = BK + 2;
 #ifndef GEMM_KX_PAD
-#define GEMM_KX_PAD 16
+#define GEMM_KX_PAD 8
 #endif
 constexpr int lds_stage(int w) {   // room for either layout
   return BK * (w + GEMM_KX_PAD) > w * LDS_XK ? BK * (w + GEMM_KX_PAD) : w * LDS_XK;
@@ -489,32 +491,35 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_lower_kernel(GemmOperands g
 // triangle (through a per-wave 16 x 16 LDS transpose so that the mirrored stores are 128-byte
 // segments too): C stays a fully stored, exactly symmetric matrix at half the MFMA work of a
 // full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
-__global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands g, double alpha,
-                                                         double* __restrict__ C, int64_t ldc,
-                                                         int tiles, int t_off) {
+template <int BN>
+__global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_kernel(
+    GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, int tiles, int t_off) {
+  // Tiles are 128 x BN. BN = 64 halves the accumulators so that THREE workgroups fit a CU: the
+  // MFMA loop (8 k-tiles at k = 128) and the read-modify-write epilogue of one workgroup are
+  // both latency-bound, and with identical tiles two co-resident workgroups run them in
+  // lockstep; a third keeps the MFMA pipe and the memory system busy at the same time.
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // De-phase the workgroups that share a CU: with identical tiles they would run their MFMA
-  // loops and their (memory-bound) epilogues in lockstep and never overlap one with the other.
-  // Only the first resident generation needs it; later workgroups inherit the phase of the
-  // slot they replace.
-  if (blockIdx.x < 1024) {
-    const unsigned h = (blockIdx.x * 2654435761u) >> 29;   // 0..7
-    for (unsigned q = 0; q < h; ++q) __builtin_amdgcn_s_sleep(127);   // 8128 cycles ~ 3.4 us each
-  }
+  constexpr int NJ = BN / 32;
+  constexpr int CPT = 128 / BN;   // tile columns per 128-wide column pair
   const int t = blockIdx.x + t_off;
-  int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t)) * 0.5);
-  while (tn > 0 && tn * tiles - tn * (tn - 1) / 2 > t) --tn;
-  while ((tn + 1) * tiles - (tn + 1) * tn / 2 <= t) ++tn;
-  const int tm = tn + (t - (tn * tiles - tn * (tn - 1) / 2));
-  const int m0 = tm * BM, n0 = tn * 128;
-  d4 acc[4][4];
-  gemm_tile<false, true, 128>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
+  // lower-triangular tiles, column by column; columns come in groups of CPT that share their
+  // first row tile p: group p has CPT * (tiles - p) tiles and starts at CPT * (p tiles - p(p-1)/2)
+  int p = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t / CPT)) * 0.5);
+  auto gstart = [&](int q) { return CPT * (q * tiles - q * (q - 1) / 2); };
+  while (p > 0 && gstart(p) > t) --p;
+  while (gstart(p + 1) <= t) ++p;
+  const int rem = t - gstart(p);
+  const int tc = CPT * p + rem / (tiles - p);          // tile column (BN wide)
+  const int tm = p + rem % (tiles - p);                // tile row (128 high)
+  const int m0 = tm * BM, n0 = tc * BN;
+  d4 acc[4][NJ];
+  gemm_tile<false, true, BN>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
   const int M = g.M;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * (BN / 2);
   const int lm = lane & 15, lk = lane >> 4;
   double* buf = smem + wave * (16 * 17);
-  const bool diag_tile = (tm == tn);
+  const bool diag_tile = (tm == p);
   // C is fetched one 64 x 16 column strip at a time, one strip ahead of the stores (vmcnt is
   // in-order over loads and stores: loads issued after a strip's stores would wait for them).
   auto load_strip = [&](int j, d4 (&cold)[4]) {
@@ -531,15 +536,14 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
   d4 coldbuf[2][4];
   load_strip(0, coldbuf[0]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j + 1 < 4) load_strip(j + 1, coldbuf[(j + 1) & 1]);
+  for (int j = 0; j < NJ; ++j) {
+    if (j + 1 < NJ) load_strip(j + 1, coldbuf[(j + 1) & 1]);
     d4 (&cold)[4] = coldbuf[j & 1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mt0 = m0 + wm + i * 16, nt0 = n0 + wn + j * 16;  // 16 x 16 sub-tile origin
       if (diag_tile && mt0 + 15 < nt0) continue;                  // entirely above the diagonal
       const int m = mt0 + lm;
-      double vals[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nt0 + lk + 4 * r;
@@ -549,7 +553,6 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_mirror_kernel(GemmOperands 
           v = cold[i][r] + alpha * acc[i][j][r];
           C[o] = v;
         }
-        vals[r] = v;
         buf[(lk + 4 * r) * 17 + lm] = v;   // buf[n_local][m_local]
       }
       // mirrored store: lane' -> (n' = nt0 + lm, m' = mt0 + lk + 4 r')
@@ -571,16 +574,19 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
   const int tiles = (int)((m + BM - 1) / BM);
   if (tn_end < 0 || tn_end > tiles) tn_end = tiles;
   if (tn_begin >= tn_end) return BIGKRLS_OK;
-  // lower-triangular tiles are enumerated column by column: column c starts at c*tiles - c(c-1)/2
-  auto first_of = [&](int64_t c) { return c * tiles - c * (c - 1) / 2; };
+  constexpr int SBN = 64;                 // tile width (see the kernel comment)
+  constexpr int CPT = 128 / SBN;
+  // tile columns of one 128-wide group q share the first row tile q: the group starts at
+  // CPT * (q tiles - q(q-1)/2)
+  auto first_of = [&](int64_t q) { return CPT * (q * tiles - q * (q - 1) / 2); };
   const int64_t t0 = first_of(tn_begin), nt = first_of(tn_end) - t0;
   static bool attr_set = false;
   if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)syrk_mirror_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
+    BK_HIP(hipFuncSetAttribute((const void*)syrk_mirror_kernel<SBN>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(SBN)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(syrk_mirror_kernel, dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
+  hipLaunchKernelGGL(syrk_mirror_kernel<SBN>, dim3((unsigned)nt), dim3(NT), smem_bytes(SBN), ctx->stream, g,
                      alpha, C, ldc, tiles, (int)t0);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
