@@ -566,15 +566,9 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   }
 }
 
-int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
-                const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin, int tn_end) {
-  if (m <= 0 || k <= 0) return BIGKRLS_OK;
-  BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror: dimension too large");
-  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
-  const int tiles = (int)((m + BM - 1) / BM);
-  if (tn_end < 0 || tn_end > tiles) tn_end = tiles;
-  if (tn_begin >= tn_end) return BIGKRLS_OK;
-  constexpr int SBN = 64;                 // tile width (see the kernel comment)
+template <int SBN>
+static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, double* C, int64_t ldc,
+                              int tiles, int tn_begin, int tn_end) {
   constexpr int CPT = 128 / SBN;
   // tile columns of one 128-wide group q share the first row tile q: the group starts at
   // CPT * (q tiles - q(q-1)/2)
@@ -590,6 +584,21 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
                      alpha, C, ldc, tiles, (int)t0);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
+}
+
+int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin, int tn_end,
+                bool narrow_tiles) {
+  if (m <= 0 || k <= 0) return BIGKRLS_OK;
+  BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror: dimension too large");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
+  const int tiles = (int)((m + BM - 1) / BM);
+  if (tn_end < 0 || tn_end > tiles) tn_end = tiles;
+  if (tn_begin >= tn_end) return BIGKRLS_OK;
+  // 128 x 64 tiles (three workgroups per CU) share the GPU better with a concurrent
+  // register-resident panel QR; alone, 128 x 128 tiles are ~6 % faster (N = 20 000: 1.65 vs 1.76 ms)
+  if (narrow_tiles) return launch_syrk_mirror<64>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
+  return launch_syrk_mirror<128>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
 }
 
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
