@@ -65,6 +65,7 @@ SIGNATURES = {
     "bigkrls_tcrossprod": [vp, i64, i64, vp, i64, vp],
     "bigkrls_xxt": [vp, i64, i64, vp],
     "bigkrls_derivmat": [vp, i64, i64, vp, vp, vp, vp, vp, f64],
+    "bigkrls_neffective": [vp, i64, i64, vp],
     # level 2
     "bigkrls_dev_kernel_block": [vp, vp, i64, i64, vp, i64, i64, i64, f64, vp, i64, i64],
     "bigkrls_dev_gemm": [vp, C.c_int, C.c_int, i64, i64, i64, f64, vp, i64, vp, i64, f64, vp, i64],
@@ -82,6 +83,7 @@ SIGNATURES = {
     "bigkrls_dev_dot": [vp, i64, vp, vp, pf64],
     "bigkrls_dev_diag": [vp, vp, i64, i64, vp],
     "bigkrls_dev_scale": [vp, i64, f64, vp],
+    "bigkrls_dev_neffective": [vp, vp, i64, i64, i64, vp],
 }
 _RESTYPES = {
     "bigkrls_last_error": C.c_char_p,

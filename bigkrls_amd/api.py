@@ -63,7 +63,7 @@ def _as_host_matrix(X) -> np.ndarray:
 
 def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None, vcov_est=True,
             Neig=None, eigtrunc=None, lambda_=None, L=None, U=None, tol=None,
-            noisy=None, ctx: Optional[Context] = None,
+            acf=False, noisy=None, ctx: Optional[Context] = None,
             timings: Optional[Dict[str, float]] = None,
             trace: Optional[list] = None) -> BigKRLS:
     """Kernel-regularised least squares fit (R/bigKRLS.R:97-516).
@@ -91,6 +91,7 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
         bad = [str(j + 1) for j in range(p) if np.isnan(Xh[:, j]).any()]
         raise ValueError("the following columns in X contain missing data, which must be removed: "
                          + ", ".join(bad))
+    acf = bool(acf) and p > 2                                                     # :192
     Neig = min(n, int(Neig)) if Neig is not None else n                           # :194
     if eigtrunc is None:                                                          # :195-201
         eigtrunc = 0.001 if n > 3000 else 0.0
@@ -198,6 +199,11 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
         avgderiv = derivmat.mean(axis=0)[None, :]                                 # :400
         varavgderivmat = ((y_init_sd / X_init_sd[cols]) ** 2 * varavgderivmat)[None, :]  # :403-407
 
+    if acf:                                                                       # :412-416
+        w["Neffective.acf"] = ops.bNeffective(Xd)
+    else:
+        w["Neffective.acf"] = None                                                # :431
+
     w["coeffs"] = coeffs                                                          # :420
     w["y"] = y_init
     w["sigma"] = sigma
@@ -237,6 +243,121 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
         T[nm] = Context.elapsed_ms(ev[i], ev[i + 1]) / 1e3
     w["_ctx"] = ctx
     return w
+
+
+def _betacf(a: float, b: float, x: float) -> float:
+    """Continued fraction of the regularised incomplete beta function (modified Lentz)."""
+    tiny = 1e-300
+    qab, qap, qam = a + b, a + 1.0, a - 1.0
+    c, d = 1.0, 1.0 - qab * x / qap
+    d = 1.0 / (d if abs(d) > tiny else tiny)
+    h = d
+    for m in range(1, 500):
+        m2 = 2 * m
+        aa = m * (b - m) * x / ((qam + m2) * (a + m2))
+        d = 1.0 + aa * d
+        d = 1.0 / (d if abs(d) > tiny else tiny)
+        c = 1.0 + aa / c
+        c = c if abs(c) > tiny else tiny
+        h *= d * c
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2))
+        d = 1.0 + aa * d
+        d = 1.0 / (d if abs(d) > tiny else tiny)
+        c = 1.0 + aa / c
+        c = c if abs(c) > tiny else tiny
+        delta = d * c
+        h *= delta
+        if abs(delta - 1.0) < 1e-16:
+            break
+    return h
+
+
+def _pt_upper(t: float, df: float) -> float:
+    """P(T > t) for Student's t with df degrees of freedom, t >= 0 (R: pt(t, df, lower.tail=FALSE)):
+    0.5 I_x(df/2, 1/2) with x = df / (df + t^2)."""
+    if not np.isfinite(t) or not df > 0:
+        return float("nan")
+    import math
+    x = df / (df + t * t)
+    a, b = 0.5 * df, 0.5
+    if x <= 0.0:
+        return 0.0
+    if x >= 1.0:
+        return 0.5
+    lbeta = math.lgamma(a + b) - math.lgamma(a) - math.lgamma(b)
+    front = math.exp(lbeta + a * math.log(x) + b * math.log1p(-x))
+    if x < (a + 1.0) / (a + b + 2.0):
+        ib = front * _betacf(a, b, x) / a
+    else:
+        ib = 1.0 - front * _betacf(b, a, 1.0 - x) / b
+    return 0.5 * ib
+
+
+def summary(object: BigKRLS, degrees: str = "Neffective", probs=(0.05, 0.25, 0.5, 0.75, 0.95),
+            digits: int = 4, labs=None, quiet: bool = False) -> Optional[dict]:
+    """summary.bigKRLS (R/bigKRLS.R:666-757): t-tests of the average marginal effects and the
+    percentiles of the pointwise marginal effects. Returns {"ttests": (P' x 4), "percentiles":
+    (P' x len(probs)), "rownames": [...]}; prints the R text unless `quiet`."""
+    if not isinstance(object, BigKRLS):
+        raise TypeError("Object not of class 'bigKRLS'")
+    if degrees not in ("acf", "Neffective", "N"):                                 # :677
+        raise ValueError('degrees must be one of "acf", "Neffective", "N"')
+    Xh = np.asarray(object["X"], dtype=np.float64)
+    N = n = Xh.shape[0]
+    if degrees == "Neffective":                                                   # :679-681
+        n = object["Neffective"]
+    if degrees == "acf":                                                          # :682-691
+        if object.get("Neffective.acf") is None:
+            ctx = object.get("_ctx") or default_context()
+            Xs = (Xh - Xh.mean(axis=0)) / Xh.std(axis=0, ddof=1)                  # scale(object$X[])
+            n = ops.bNeffective(ctx.from_numpy(Xs))
+        else:
+            n = object["Neffective.acf"]
+    say = (lambda *a: None) if quiet else (lambda *a: print(*a))
+    say("\n\nMODEL SUMMARY:\n")
+    say("lambda:", round(object["lambda"], digits))
+    say("N:", N)
+    if n != N:
+        say("N Effective:", n)
+    p = Xh.shape[1]
+    say("R2:", round(float(object["R2"]), digits))
+    if object.get("derivatives") is None:                                         # :700-703
+        say("\nrecompute with bigKRLS(..., derivative = TRUE) for estimates of marginal effects\n")
+        return None
+    if object.get("R2AME") is not None:
+        say("R2AME**:", round(float(object["R2AME"]), digits), "\n")
+    if labs is not None:                                                          # :708-714
+        if len(labs) != p:
+            raise ValueError("length(labs) must equal ncol(X)")
+        names = list(labs)
+    else:
+        names = list(object["xlabs"])
+    which = object.get("which.derivatives") or list(range(1, p + 1))              # :716-718
+    est = np.asarray(object["avgderivatives"], dtype=np.float64).ravel()          # :720
+    se = np.sqrt(np.asarray(object["var.avgderivatives"], dtype=np.float64).ravel())
+    if degrees != "Neffective":                                                   # :722-724
+        se = se * N / n
+    tval = est / se
+    pval = np.array([2.0 * _pt_upper(abs(t), n - p) for t in tval])              # :726
+    AME = np.column_stack([est, se, tval, pval])
+    isbin = np.asarray(object["binaryindicator"], dtype=bool)
+    rown = [names[i - 1] + ("*" if isbin[i - 1] else "") for i in which]          # :729-733
+    deriv = np.asarray(object["derivatives"], dtype=np.float64).reshape(N, len(which))
+    qderiv = np.quantile(deriv, list(probs), axis=0).T                            # R quantile type 7
+    say("Average Marginal Effects:\n")
+    say("%-12s %12s %12s %12s %12s" % ("", "Estimate", "Std. Error", "t value", "Pr(>|t|)"))
+    for nm, row in zip(rown, np.round(AME, digits)):
+        say("%-12s %12g %12g %12g %12g" % (nm, *row))
+    say("\n\nPercentiles of Marginal Effects:\n")
+    say("%-12s " % "" + " ".join("%11s%%" % (100 * q) for q in probs))
+    for nm, row in zip(rown, np.round(qderiv, digits)):
+        say("%-12s " % nm + " ".join("%12g" % v for v in row))
+    if isbin.any():
+        say("\n(*) Reported average and percentiles of dy/dx is for discrete change of the dummy "
+            "variable from min to max (usually 0 to 1)).\n")
+    say("\n(**) Pseudo-R^2 computed using only the Average Marginal Effects.")
+    return {"ttests": AME, "percentiles": qderiv, "rownames": rown,
+            "colnames": ["Estimate", "Std. Error", "t value", "Pr(>|t|)"], "n": n}
 
 
 def predict(object: BigKRLS, newdata, se_pred=False, correct_SE=True, ytest=None,

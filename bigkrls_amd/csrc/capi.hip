@@ -582,6 +582,22 @@ __global__ void l1_coldots_kernel(int n, int p, const double* __restrict__ S,
   if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+int bigkrls_neffective(const double* X, int64_t n, int64_t p, double* neff) {
+  BK_REQUIRE(X && neff && n > 0 && p > 0, "neffective: bad arguments");
+  bigkrls_ctx* ctx;
+  BK_TRY(default_ctx(&ctx));
+  BK_TRY(check_ctx(ctx));
+  DevBuf dX;
+  BK_TRY(dX.upload(ctx, X, n * p));
+  return neffective(ctx, dX.p, n, n, p, neff);
+}
+
+int bigkrls_dev_neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p,
+                           double* h_neff) {
+  BK_TRY(check_ctx(ctx));
+  return neffective(ctx, X, n, ldx, p, h_neff);
+}
+
 int bigkrls_derivmat(const double* X, int64_t n, int64_t p, const double* K, const double* V,
                      double* D, double* var, const double* coeffs, double sigma) {
   BK_REQUIRE(X && K && V && D && var && coeffs && n > 0 && p > 0, "derivmat: bad arguments");

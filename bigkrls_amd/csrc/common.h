@@ -115,6 +115,9 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
                 int tn_end = -1, bool narrow_tiles = false);
 int side_stream_get(bigkrls_ctx* ctx);
 
+// effective sample size from the mean absolute pairwise row correlation (src/Neffective.cpp)
+int neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p, double* h_out);
+
 // batched GEMM for the divide & conquer merges: per-problem descriptors on device
 struct GemmDesc {
   const double* A;

@@ -40,6 +40,15 @@ def bGaussKernel(X: DeviceMatrix, bandwidth: Optional[float] = None,
     return out
 
 
+def bNeffective(X: DeviceMatrix) -> float:
+    """Effective sample size as a function of the mean absolute pairwise correlation of the
+    rows of X (bNeffective, R/bigKRLS_Rcpp_functions.R:212-217 -> BigNeffective,
+    src/Neffective.cpp:13-76)."""
+    out = np.zeros(1, dtype=np.float64)
+    _lib.call("bigkrls_dev_neffective", X.ctx.handle, X.ptr, X.nrow, X.ld, X.ncol, _hptr(out))
+    return float(out[0])
+
+
 def bTempKernel(X_new: DeviceMatrix, X_old: DeviceMatrix, sigma: float) -> DeviceMatrix:
     """out[i,j] = exp(-||new_i - old_j||^2/sigma)  (bTempKernel, :219-227)."""
     ctx = X_new.ctx

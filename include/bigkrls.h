@@ -128,6 +128,11 @@ int bigkrls_xxt(const double* A, int64_t n, int64_t k, double* out);
 int bigkrls_derivmat(const double* X, int64_t n, int64_t p, const double* K, const double* V,
                      double* D, double* var, const double* coeffs, double sigma);
 
+/* replaces double BigNeffective(pX)                       src/Neffective.cpp:13-65, 67-76
+ * X n x p; *neff = n (1 - 2 r / n^2) + 1 with r = sum_{i>j} |cor(row i, row j)|
+ * (rows de-meaned and normalised). A constant row gives NaN, as in the reference. */
+int bigkrls_neffective(const double* X, int64_t n, int64_t p, double* neff);
+
 /* =============================================================================
  * Level 2: device-resident operators (all pointers are device pointers unless
  * the parameter name starts with h_)
@@ -214,6 +219,10 @@ int bigkrls_dev_gemv(bigkrls_ctx* ctx, int trans, int64_t m, int64_t n, double a
 int bigkrls_dev_dot(bigkrls_ctx* ctx, int64_t n, const double* x, const double* y, double* h_out);
 int bigkrls_dev_diag(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, double* out);
 int bigkrls_dev_scale(bigkrls_ctx* ctx, int64_t n, double alpha, double* x);
+
+/* device-resident BigNeffective: X n x p on device (leading dimension ldx), result on host */
+int bigkrls_dev_neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p,
+                           double* h_neff);
 
 #ifdef __cplusplus
 }

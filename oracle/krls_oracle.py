@@ -534,6 +534,46 @@ def fit(y, X, sigma=None, derivative=True, which_derivatives: Optional[Sequence[
 # --------------------------------------------------------------------------
 # predict (R/bigKRLS.R:547-637)
 # --------------------------------------------------------------------------
+def neffective_literal(X: np.ndarray) -> float:
+    """xBigNeffective, src/Neffective.cpp:13-65: rows de-meaned and normalised (:29-44), r = sum over
+    i > j of |z_i . z_j| (:52-55; `abs` of a double), Neffective = N (1 - 2r/N^2) + 1 (:61-64)."""
+    X = np.asarray(X, dtype=np.float64)
+    n = X.shape[0]
+    Z = X - X.mean(axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        Z = Z / np.sqrt((Z * Z).sum(axis=1, keepdims=True))
+    r = 0.0
+    for i0 in range(0, n, 1024):                      # blocks of rows of the strict lower triangle
+        G = np.abs(Z[i0:i0 + 1024] @ Z.T)
+        rows = np.arange(i0, min(n, i0 + 1024))[:, None]
+        r += float(np.where(np.arange(n)[None, :] < rows, G, 0.0).sum())
+    return n * (1.0 - 2.0 * r / float(n) ** 2) + 1.0
+
+
+def summary_tables(obj: Dict[str, object], degrees: str = "Neffective", probs=(0.05, 0.25, 0.5, 0.75, 0.95)):
+    """The numbers of summary.bigKRLS (R/bigKRLS.R:666-757): est, se (rescaled by N/n unless
+    degrees == "Neffective", :722-724), t, p = 2 pt(|t|, n - p, lower=FALSE) (:726), and the
+    percentiles of the pointwise marginal effects (:741-742, R quantile type 7)."""
+    from scipy import stats
+    X = np.asarray(obj["X"], dtype=np.float64)
+    N, p = X.shape
+    n = float(N)
+    if degrees == "Neffective":
+        n = float(obj["Neffective"])
+    elif degrees == "acf":
+        Xs = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
+        n = neffective_literal(Xs)
+    est = np.asarray(obj["avgderivatives"], dtype=np.float64).ravel()
+    se = np.sqrt(np.asarray(obj["var.avgderivatives"], dtype=np.float64).ravel())
+    if degrees != "Neffective":
+        se = se * N / n
+    tval = est / se
+    pval = 2.0 * stats.t.sf(np.abs(tval), n - p)
+    D = np.asarray(obj["derivatives"], dtype=np.float64)
+    return {"ttests": np.column_stack([est, se, tval, pval]),
+            "percentiles": np.quantile(D, list(probs), axis=0).T, "n": n}
+
+
 def predict(obj: Dict[str, object], newdata: np.ndarray, se_pred=False, correct_se=True):
     X = np.asarray(obj["X"], dtype=np.float64)
     newdata = np.array(newdata, dtype=np.float64)

@@ -84,3 +84,14 @@ def test_partition_covers_rows_once():
             assert parts[0][0] == 0 and parts[-1][1] == n and nb * world >= n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             assert all(b - a <= nb for a, b in parts)
+
+
+def test_summary_student_t_tail_matches_scipy():
+    """Host logic of summary(): pt(|t|, df, lower.tail=FALSE) (R/bigKRLS.R:726) is restated with an
+    incomplete-beta continued fraction; check it against scipy's Student t survival function."""
+    from scipy import stats
+    from bigkrls_amd import api
+    for df in (0.7, 3.0, 17.5, 396.2, 19752.1, 1e6):
+        for t in (0.0, 1e-3, 0.5, 1.96, 5.0, 12.0, 40.0):
+            a, b = api._pt_upper(t, df), stats.t.sf(t, df)
+            assert abs(a - b) <= 1e-7 * b + 1e-300, (t, df, a, b)

@@ -193,3 +193,42 @@ def test_dist_path_world1_hip_backend(ctx):
     assert rel(out["K.cols"].cpu().numpy().T, ref["K"]) < 1e-12
     assert rel(out["vcov.est.c.cols"].cpu().numpy().T, ref["vcov.est.c"]) < TOL
     assert rel(out["vcov.est.fitted.cols"].cpu().numpy().T, ref["vcov.est.fitted"]) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(1, 3), (2, 3), (33, 4), (500, 5), (1000, 20), (2049, 7), (777, 130)])
+def test_neffective_matches_oracle(n, p):
+    """bigkrls_neffective (Level 1, host pointers) and ops.bNeffective (device) vs the literal oracle."""
+    import ctypes as C
+    import bigkrls_amd as bk
+    from bigkrls_amd import _lib, ops
+    rng = np.random.default_rng(n + p)
+    X = rng.standard_normal((n, p)) + 0.3 * rng.standard_normal((n, 1))
+    ref = orc.neffective_literal(X)
+    Xf = np.asfortranarray(X)
+    out = np.zeros(1)
+    _lib.call("bigkrls_neffective", Xf.ctypes.data_as(C.c_void_p), n, p, out.ctypes.data_as(C.c_void_p))
+    assert abs(out[0] - ref) <= 1e-10 * abs(ref), (out[0], ref)
+    ctx = bk.Context(0)
+    got = ops.bNeffective(ctx.from_numpy(X))
+    assert got == out[0]                      # same kernel, deterministic reduction
+
+
+@pytest.mark.gpu
+def test_acf_and_summary_match_oracle():
+    """bigKRLS(acf=TRUE) stores Neffective.acf of the standardised X (R/bigKRLS.R:412-416); summary()
+    reproduces the t-tests and percentiles of summary.bigKRLS for all three `degrees` choices."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(400, 4, 77, binary_last=True)
+    out = bk.bigKRLS(y, X, acf=True)
+    Xs = (X - X.mean(axis=0)) / X.std(axis=0, ddof=1)
+    assert abs(out["Neffective.acf"] - orc.neffective_literal(Xs)) < 1e-9 * 400
+    ref_fit = orc.fit(y, X, literal=False)
+    for deg in ("Neffective", "N", "acf"):
+        s = bk.summary(out, degrees=deg, quiet=True)
+        r = orc.summary_tables(ref_fit, degrees=deg)
+        assert s["rownames"] == ["x1", "x2", "x3", "x4*"]
+        assert np.allclose(s["ttests"][:, :3], r["ttests"][:, :3], rtol=1e-6, atol=0)
+        assert np.allclose(s["ttests"][:, 3], r["ttests"][:, 3], rtol=1e-6, atol=1e-300)
+        assert np.allclose(s["percentiles"], r["percentiles"], rtol=1e-6, atol=1e-12)
+    assert bk.bigKRLS(y, X[:, :2], acf=True)["Neffective.acf"] is None     # acf <- acf & p > 2 (:192)
