@@ -9,7 +9,8 @@ loudly if the shared library or a HIP device is missing.
 from ._lib import BigKRLSError, LIB_PATH  # noqa: F401
 from .api import BigKRLS, BigKRLSPredicted, bigKRLS, crossvalidate, predict, summary  # noqa: F401
 from .device import Context, DeviceMatrix  # noqa: F401
+from .persist import load_bigKRLS, save_bigKRLS  # noqa: F401
 from . import ops  # noqa: F401
 
-__all__ = ["bigKRLS", "predict", "crossvalidate", "summary", "Context", "DeviceMatrix", "ops",
+__all__ = ["bigKRLS", "predict", "crossvalidate", "summary", "save_bigKRLS", "load_bigKRLS", "Context", "DeviceMatrix", "ops",
            "BigKRLS", "BigKRLSPredicted", "BigKRLSError", "LIB_PATH"]

@@ -2,6 +2,8 @@
 
 Tolerance: north_star asks for 1e-6 relative fp64 on coefficients, fitted values,
 lambda and pointwise derivatives; written as TOL below."""
+import os
+
 import numpy as np
 import pytest
 
@@ -232,3 +234,28 @@ def test_acf_and_summary_match_oracle():
         assert np.allclose(s["ttests"][:, 3], r["ttests"][:, 3], rtol=1e-6, atol=1e-300)
         assert np.allclose(s["percentiles"], r["percentiles"], rtol=1e-6, atol=1e-12)
     assert bk.bigKRLS(y, X[:, :2], acf=True)["Neffective.acf"] is None     # acf <- acf & p > 2 (:192)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary", [False, True])
+def test_save_load_round_trip(tmp_path, binary):
+    """save.bigKRLS / load.bigKRLS round trip (the reference pins exactly this:
+    tests/testthat/test_basic_usage.R:53-61, :123-128): device-resident matrices come back equal,
+    and the reloaded object predicts identically."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(2600, 3, 5)               # n > 2500: K and the variance matrices stay on the device
+    out = bk.bigKRLS(y, X, eigtrunc=0.01)
+    folder = bk.save_bigKRLS(out, str(tmp_path / "model"), noisy=False, binary=binary)
+    assert os.path.exists(os.path.join(folder, "K.npy" if binary else "K.txt"))
+    back = bk.load_bigKRLS(folder, noisy=False)
+    for k in ("coeffs", "yfitted", "derivatives", "avgderivatives", "var.avgderivatives", "X", "y"):
+        assert np.array_equal(np.asarray(back[k]), np.asarray(out[k])), k
+    for k in ("lambda", "R2", "Neffective", "sigma", "Looe", "lastkeeper"):
+        assert back[k] == out[k], k
+    for k in ("K", "vcov.est.c", "vcov.est.fitted"):
+        assert np.array_equal(back[k].to_numpy(), out[k].to_numpy()), k
+    p0 = bk.predict(out, X[:20] + 0.05, se_pred=True)
+    p1 = bk.predict(back, X[:20] + 0.05, se_pred=True)
+    assert np.array_equal(p0["predicted"], p1["predicted"]) and np.array_equal(p0["se.pred"], p1["se.pred"])
+    again = bk.save_bigKRLS(out, str(tmp_path / "model"), noisy=False, binary=binary)   # existing folder is not reused
+    assert again != folder and os.path.isdir(again)
