@@ -27,6 +27,7 @@ _lib: Optional[C.CDLL] = None
 i64 = C.c_int64
 f64 = C.c_double
 vp = C.c_void_p
+i32 = C.c_int32
 pf64 = C.POINTER(C.c_double)
 pi64 = C.POINTER(C.c_int64)
 pi32 = C.POINTER(C.c_int32)
@@ -71,6 +72,7 @@ SIGNATURES = {
     "bigkrls_dev_gemm": [vp, C.c_int, C.c_int, i64, i64, i64, f64, vp, i64, vp, i64, f64, vp, i64],
     "bigkrls_dev_multdiag": [vp, vp, i64, i64, i64, vp, vp, i64],
     "bigkrls_dev_eigen": [vp, vp, i64, i64, i64, vp, i64, f64, vp, i64, pi64],
+    "bigkrls_dev_eigen_part": [vp, vp, i64, i64, i64, vp, i64, f64, vp, i64, pi64, i32, i32],
     "bigkrls_dev_qty": [vp, vp, i64, i64, i64, vp, vp],
     "bigkrls_dev_solveforc": [vp, vp, i64, i64, i64, vp, vp, f64, vp, pf64],
     "bigkrls_dev_lambda_search": [vp, vp, i64, i64, i64, vp, vp, vp, i64, f64, f64, f64,

@@ -385,6 +385,14 @@ int bigkrls_dev_eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda,
   return eigen(ctx, A, n, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs);
 }
 
+int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals,
+                           double* vals, int64_t n_vecs_max, double keep_thresh, double* vecs,
+                           int64_t ldv, int64_t* h_n_vecs, int32_t part_index, int32_t part_count) {
+  BK_TRY(check_ctx(ctx));
+  return eigen(ctx, A, n, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
+               part_count);
+}
+
 int bigkrls_dev_qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
                     const double* y, double* a) {
   BK_TRY(check_ctx(ctx));

@@ -163,6 +163,7 @@ int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t l
 
 // ---- eigen.hip ----------------------------------------------------------------
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals, double* vals,
-          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs);
+          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
+          int part_index = 0, int part_count = 1);
 
 }  // namespace bk

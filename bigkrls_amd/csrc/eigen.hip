@@ -1140,7 +1140,9 @@ int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, 
 }  // namespace
 
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
-          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs) {
+          int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
+          int part_index, int part_count) {
+  BK_REQUIRE(part_count >= 1 && part_index >= 0 && part_index < part_count, "eigen: bad column partition");
   BK_REQUIRE(A && vals && n64 > 0 && n64 < (1ll << 30), "eigen: bad matrix");
   BK_REQUIRE(n_vals > 0 && n_vals <= n64, "eigen: n_vals out of range");
   BK_REQUIRE(n_vecs_max >= 0 && n_vecs_max <= n64, "eigen: n_vecs_max out of range");
@@ -1256,14 +1258,23 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     hipLaunchKernelGGL(gather_cols, dim3(blocks), dim3(256), 0, st, n, nv, (const int*)d_src,
                        (const double*)Qfin, N, vecs, ldv);
     BK_CHECK_LAUNCH();
-    if (two_stage) {
-      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, vecs, ldv, nv));
+    // Multi-GPU: every rank runs the (replicated) reduction and divide & conquer, but
+    // back-transforms only its own slice of the kept eigenvector columns; the other columns are
+    // returned as zeros, so that an all-reduce (sum) over the ranks assembles Q exactly.
+    const int pc0 = (int)((int64_t)nv * part_index / part_count);
+    const int pc1 = (int)((int64_t)nv * (part_index + 1) / part_count);
+    if (pc0 > 0) BK_HIP(hipMemsetAsync(vecs, 0, (size_t)pc0 * ldv * sizeof(double), st));
+    if (pc1 < nv) BK_HIP(hipMemsetAsync(vecs + (int64_t)pc1 * ldv, 0, (size_t)(nv - pc1) * ldv * sizeof(double), st));
+    double* pvecs = vecs + (int64_t)pc0 * ldv;
+    const int pnv = pc1 - pc0;
+    if (pnv > 0 && two_stage) {
+      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv));
       void* pw12 = nullptr;
-      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * nv * sizeof(double), &pw12));
-      BK_TRY(back_transform_stage1(ctx, W, n, taus1, vecs, ldv, nv, s1.Vp, s1.Tall, (double*)pw12,
-                                   (double*)pw12 + (int64_t)S2_B * nv));
-    } else {
-      BK_TRY(back_transform(ctx, W, n, tau, vecs, ldv, nv));
+      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * pnv * sizeof(double), &pw12));
+      BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
+                                   (double*)pw12 + (int64_t)S2_B * pnv));
+    } else if (pnv > 0) {
+      BK_TRY(back_transform(ctx, W, n, tau, pvecs, ldv, pnv));
     }
   }
   BK_HIP(hipStreamSynchronize(st));

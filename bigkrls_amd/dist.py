@@ -6,9 +6,9 @@ symmetric, so the row block is stored as the contiguous column block K[:, r0:r1]
 
   phase            local work                         exchange
   kernel build     K[:, r0:r1] (fp64 MFMA + exp)       all-gather of the column blocks
-  eigen            replicated (round 1; the N x N       none
-                   tridiagonalisation is not yet
-                   distributed -- section 8(f))
+  eigen            reduction + divide&conquer          all-reduce (sum) of Q: every rank
+                   replicated (not yet distributed     back-transforms its own slice of the
+                   -- section 8(f))                     eigenvector columns, zeros elsewhere
   lambda search    Q[r0:r1,:]: a_r = Q_r' y_r          all-reduce a (K doubles) once,
                    per probe c_r, g_r, Le_r             all-reduce of one scalar per probe
   coefficients     c_r                                  all-gather c (N doubles)
@@ -65,8 +65,10 @@ class HipBackend:
         _lib.call("bigkrls_dev_kernel_block", self.ctx.handle, Xd.ptr, n, n, Xd.col_ptr(0, c0),
                   c1 - c0, n, p, float(sigma), C.c_void_p(out.data_ptr()), n, c0)
 
-    def eigen(self, K, neig, eigtrunc):
-        eo = ops.bEigen(self._dm(K), neig, eigtrunc)
+    def eigen(self, K, neig, eigtrunc, rank=0, world=1):
+        """Replicated reduction + divide & conquer; this rank's slice of the eigenvector columns
+        back-transformed, zeros elsewhere (the caller all-reduces Q)."""
+        eo = ops.bEigen(self._dm(K), neig, eigtrunc, part=(rank, world) if world > 1 else None)
         return eo.values, eo.lastkeeper, eo.vectors.t, eo.values_dev.t
 
     def qty_rows(self, Q, r0, r1, y):
@@ -208,7 +210,11 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     Kcols = K[r0:r1]
     mark("kernel_allgather")
     # ---- step 2: eigen (replicated) -------------------------------------------------
-    vals, lastkeeper, Q, dvals = backend.eigen(K, Neig, eigtrunc)
+    vals, lastkeeper, Q, dvals = backend.eigen(K, Neig, eigtrunc, rank, world)
+    if world > 1:
+        # each rank back-transformed its own eigenvector columns (zeros elsewhere): sum = Q.
+        # This is the RCCL exchange north_star names for the eigenvector back-transform.
+        dist.all_reduce(Q, op=dist.ReduceOp.SUM)
     mark("eigen")
     # ---- step 3: lambda search on row blocks of Q ------------------------------------
     a = backend.qty_rows(Q, r0, r1, yd)

@@ -71,10 +71,13 @@ class Eigenobject:
     values_dev: DeviceMatrix    # the same eigenvalues on the device
 
 
-def bEigen(A: DeviceMatrix, Neig: Optional[int] = None, eigtrunc: float = 0.0) -> Eigenobject:
+def bEigen(A: DeviceMatrix, Neig: Optional[int] = None, eigtrunc: float = 0.0,
+           part: Optional[Tuple[int, int]] = None) -> Eigenobject:
     """bEigen (:173-199): all Neig eigenvalues are kept, eigenvectors only for
     1..lastkeeper = max(which(values >= eigtrunc*values[1])) (:190).  The sign flip
-    at :186 is immaterial (quirk Q9) and not reproduced."""
+    at :186 is immaterial (quirk Q9) and not reproduced.  `part=(rank, world)` (multi-GPU):
+    only this rank's slice of the kept eigenvector columns is back-transformed, the others
+    are zeros (sum over ranks = Q)."""
     ctx = A.ctx
     n = A.nrow
     if A.ncol != n:
@@ -85,8 +88,12 @@ def bEigen(A: DeviceMatrix, Neig: Optional[int] = None, eigtrunc: float = 0.0) -
     vals = ctx.empty(Neig, 1)
     vecs = ctx.empty(n, Neig)
     nv = C.c_int64(0)
-    _lib.call("bigkrls_dev_eigen", ctx.handle, A.ptr, n, A.ld, Neig, vals.ptr, Neig,
-              float(eigtrunc), vecs.ptr, vecs.ld, C.byref(nv))
+    if part is None:
+        _lib.call("bigkrls_dev_eigen", ctx.handle, A.ptr, n, A.ld, Neig, vals.ptr, Neig,
+                  float(eigtrunc), vecs.ptr, vecs.ld, C.byref(nv))
+    else:
+        _lib.call("bigkrls_dev_eigen_part", ctx.handle, A.ptr, n, A.ld, Neig, vals.ptr, Neig,
+                  float(eigtrunc), vecs.ptr, vecs.ld, C.byref(nv), int(part[0]), int(part[1]))
     values = vals.to_numpy().ravel()
     lastkeeper = int(nv.value)
     return Eigenobject(values=values, lastkeeper=lastkeeper, vectors=vecs.cols(0, lastkeeper),

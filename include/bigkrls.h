@@ -167,6 +167,17 @@ int bigkrls_dev_eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda,
                       int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
                       int64_t* h_n_vecs);
 
+/* Multi-GPU variant (one process per GPU, the same A on every rank): everything up to and
+ * including the divide & conquer is replicated, but only the slice
+ * [n_vecs*part_index/part_count, n_vecs*(part_index+1)/part_count) of the kept eigenvector
+ * columns is back-transformed; the other columns of vecs are returned as zeros, so that an
+ * all-reduce (sum) of vecs over the ranks -- the RCCL exchange north_star names for the
+ * eigenvector back-transform -- assembles Q exactly. part_count = 1 is bigkrls_dev_eigen. */
+int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda,
+                           int64_t n_vals, double* vals,
+                           int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
+                           int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
+
 /* a = Q'y (k-vector), hoisted out of the lambda probes. Q rows [0,n), ld ldq. */
 int bigkrls_dev_qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
                     const double* y, double* a);

@@ -32,10 +32,15 @@ class NumpyBackend:
         for c in range(c0, c1):
             out[c - c0, c] = 1.0
 
-    def eigen(self, K, neig, eigtrunc):
+    def eigen(self, K, neig, eigtrunc, rank=0, world=1):
         eo = orc.b_eigen(K.numpy().T, neig, eigtrunc)
-        return eo.values, eo.lastkeeper, torch.from_numpy(np.ascontiguousarray(eo.vectors.T)), \
-            torch.from_numpy(eo.values.copy())[None, :]
+        V = np.ascontiguousarray(eo.vectors.T)           # (lastkeeper, n)
+        if world > 1:                                     # same contract as bigkrls_dev_eigen_part
+            nv = V.shape[0]
+            c0, c1 = nv * rank // world, nv * (rank + 1) // world
+            V[:c0] = 0.0
+            V[c1:] = 0.0
+        return eo.values, eo.lastkeeper, torch.from_numpy(V), torch.from_numpy(eo.values.copy())[None, :]
 
     def qty_rows(self, Q, r0, r1, y):
         return torch.from_numpy((Q.numpy()[:, r0:r1] @ y.numpy().ravel()[r0:r1])[None, :].copy())
@@ -109,9 +114,9 @@ def main():
     be = NumpyBackend()
     # the test double needs the full K for its derivative identities: capture it from the all-gather
     orig_eigen = be.eigen
-    def eigen_capture(K, neig, eigtrunc):
+    def eigen_capture(K, neig, eigtrunc, rank=0, world=1):
         be._Kfull = K.numpy().T.copy()
-        return orig_eigen(K, neig, eigtrunc)
+        return orig_eigen(K, neig, eigtrunc, rank, world)
     be.eigen = eigen_capture
     tr = []
     out = bkdist.bigKRLS_dist(y, X, backend=be, trace=tr)

@@ -259,3 +259,27 @@ def test_save_load_round_trip(tmp_path, binary):
     assert np.array_equal(p0["predicted"], p1["predicted"]) and np.array_equal(p0["se.pred"], p1["se.pred"])
     again = bk.save_bigKRLS(out, str(tmp_path / "model"), noisy=False, binary=binary)   # existing folder is not reused
     assert again != folder and os.path.isdir(again)
+
+
+@pytest.mark.gpu
+def test_eigen_column_partition_sums_to_full():
+    """bigkrls_dev_eigen_part: the slices back-transformed by the ranks of a multi-GPU run are
+    disjoint column blocks whose sum is the eigenvector matrix of the single-GPU call."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    ctx = bk.Context(0)
+    X, y = orc.synth(700, 4, 11)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), 4.0)
+    full = ops.bEigen(K, 700, 0.001)
+    Qf = full.vectors.to_numpy()
+    acc = np.zeros_like(Qf)
+    for r in range(3):
+        part = ops.bEigen(K, 700, 0.001, part=(r, 3))
+        assert part.lastkeeper == full.lastkeeper and np.array_equal(part.values, full.values)
+        Qp = part.vectors.to_numpy()
+        nv = full.lastkeeper
+        c0, c1 = nv * r // 3, nv * (r + 1) // 3
+        assert not Qp[:, :c0].any() and not Qp[:, c1:].any()
+        acc += Qp
+    assert np.array_equal(acc, Qf)
