@@ -57,6 +57,25 @@ int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out) {
   return BIGKRLS_OK;
 }
 
+int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes) {
+  for (const void* k : ctx->dyn_smem_done)
+    if (k == kernel) return BIGKRLS_OK;
+  BK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  ctx->dyn_smem_done.push_back(kernel);
+  return BIGKRLS_OK;
+}
+
+int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap) {
+  for (auto& kv : ctx->resident_cap)
+    if (kv.first == kernel) { *cap = kv.second; return BIGKRLS_OK; }
+  int per_cu = 0, ncu = 0;
+  BK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+  BK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  *cap = std::max(1, per_cu * ncu);
+  ctx->resident_cap.emplace_back(kernel, *cap);
+  return BIGKRLS_OK;
+}
+
 int side_stream_get(bigkrls_ctx* ctx) {
   if (!ctx->side_stream) {
     // highest priority: its short latency-bound launches must not queue behind the thousands of

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bigkrls.h"
@@ -47,6 +48,10 @@ struct bigkrls_ctx {
   bool owns_stream = false;
   // side stream + events for look-ahead inside the eigensolver (panel QR of the next block
   // column runs concurrently with the rest of the trailing update); created on first use
+  // per-context (== per-device) launch set-up that must not be cached process-wide: kernels whose
+  // dynamic-LDS limit was raised, and co-resident workgroup capacities of the persistent kernels
+  std::vector<const void*> dyn_smem_done;
+  std::vector<std::pair<const void*, int>> resident_cap;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
@@ -114,6 +119,10 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
                 const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin = 0,
                 int tn_end = -1, bool narrow_tiles = false);
 int side_stream_get(bigkrls_ctx* ctx);
+// raise a kernel's dynamic shared-memory limit once per context (device)
+int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes);
+// co-resident workgroups of `kernel` (256 threads, static LDS only) on this context's device
+int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap);
 
 // effective sample size from the mean absolute pairwise row correlation (src/Neffective.cpp)
 int neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p, double* h_out);

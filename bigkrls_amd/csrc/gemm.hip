@@ -398,12 +398,7 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
     partial = (double*)p;
   }
   auto kern = gemm_kernel<TA, TB, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem_bytes(BN)));
-    attr_set = true;
-  }
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)kern, smem_bytes(BN)));
   dim3 grid(ntile, splits);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem_bytes(BN), ctx->stream, g, alpha, beta, C, ldc,
                      tiles_m, tiles_n, k_chunk, partial);
@@ -574,12 +569,7 @@ static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double al
   // CPT * (q tiles - q(q-1)/2)
   auto first_of = [&](int64_t q) { return CPT * (q * tiles - q * (q - 1) / 2); };
   const int64_t t0 = first_of(tn_begin), nt = first_of(tn_end) - t0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)syrk_mirror_kernel<SBN>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(SBN)));
-    attr_set = true;
-  }
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN>, smem_bytes(SBN)));
   hipLaunchKernelGGL(syrk_mirror_kernel<SBN>, dim3((unsigned)nt), dim3(NT), smem_bytes(SBN), ctx->stream, g,
                      alpha, C, ldc, tiles, (int)t0);
   BK_CHECK_LAUNCH();
@@ -608,12 +598,7 @@ int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doubl
   GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
   const int tiles = (int)((m + BM - 1) / BM);
   const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)syrk_lower_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
-    attr_set = true;
-  }
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_lower_kernel, smem_bytes(128)));
   hipLaunchKernelGGL(syrk_lower_kernel, dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
                      alpha, C, ldc, tiles);
   BK_CHECK_LAUNCH();
@@ -644,12 +629,7 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_batched_nn_kernel(const Gem
 int gemm_batched_nn(bigkrls_ctx* ctx, const GemmDesc* d_descs, int n_batch, int max_m, int max_n) {
   if (n_batch <= 0 || max_m <= 0 || max_n <= 0) return BIGKRLS_OK;
   const int tiles_m = (max_m + BM - 1) / BM, tiles_n = (max_n + 127) / 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)gemm_batched_nn_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(128)));
-    attr_set = true;
-  }
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)gemm_batched_nn_kernel, smem_bytes(128)));
   // grid.y is limited to 65535
   for (int b0 = 0; b0 < n_batch; b0 += 65535) {
     const int nb = std::min(65535, n_batch - b0);
@@ -1048,12 +1028,7 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   GemmOperands g{A, B, lda, ldb, (int)u, (int)v, (int)p, nullptr};
   constexpr int KBN = 64;
   const int tiles_m = (int)((u + BM - 1) / BM), tiles_n = (int)((v + KBN - 1) / KBN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    BK_HIP(hipFuncSetAttribute((const void*)kernel_block_kernel<KBN>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(KBN)));
-    attr_set = true;
-  }
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)kernel_block_kernel<KBN>, smem_bytes(KBN)));
   BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
   hipLaunchKernelGGL(kernel_block_kernel<KBN>, dim3(tiles_m * tiles_n), dim3(NT), smem_bytes(KBN),
                      ctx->stream, g, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
