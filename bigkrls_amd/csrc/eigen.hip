@@ -598,17 +598,35 @@ __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ 
   lo = fmin(lo, hi) * (1.0 - 8.0 * DEPS);
   if (!(lo > 0.0)) lo = hi * 1e-300;
   const double dorg = dl[org];
-  for (int it = 0; it < 400; ++it) {
-    if (!(hi > lo)) break;
-    const double mid = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
-    if (!(mid > lo) || !(mid < hi)) break;
-    const double tau = sgn * mid;
-    double g = 0.0;
-    for (int i = lane; i < K; i += 64) g += ww[i] * ww[i] / ((dl[i] - dorg) - tau);
+  // Safeguarded Newton inside the bracket [lo, hi] (in |tau|): every evaluation yields f, f' and
+  // the sum of absolute terms (the rounding-error scale of f); the bracket is updated from the
+  // sign of f, the Newton step is taken when it stays strictly inside the bracket and otherwise
+  // the (geometric) midpoint. Stops when |f| is at the rounding level of its own evaluation
+  // (LAPACK dlaed4's criterion) or the bracket has collapsed; the bisection alone needed ~60-100
+  // evaluations per root, this needs ~6-12.
+  double x = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
+  for (int it = 0; it < 200; ++it) {
+    if (!(hi > lo) || !(x > lo) || !(x < hi)) break;
+    const double tau = sgn * x;
+    double g = 0.0, gp = 0.0, ga = 0.0;
+    for (int i = lane; i < K; i += 64) {
+      const double inv = 1.0 / ((dl[i] - dorg) - tau);
+      const double t = ww[i] * ww[i] * inv;
+      g += t;
+      gp += t * inv;
+      ga += fabs(t);
+    }
     g = 1.0 + rho * wsum(g);
+    gp = rho * wsum(gp);          // df/dtau > 0
+    ga = 1.0 + rho * wsum(ga);
     const bool pos = (g >= 0.0);
-    if (sgn > 0.0) { if (pos) hi = mid; else lo = mid; }
-    else           { if (pos) lo = mid; else hi = mid; }
+    if (sgn > 0.0) { if (pos) hi = x; else lo = x; }
+    else           { if (pos) lo = x; else hi = x; }
+    if (fabs(g) <= 8.0 * DEPS * ga) { lo = x; hi = x; break; }
+    // Newton in tau = sgn * x:  tau_new = tau - g / gp
+    const double xn = sgn * (tau - g / gp);
+    const double mid = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
+    x = (xn > lo && xn < hi) ? xn : mid;
   }
   const double tau = sgn * 0.5 * (lo + hi);
   if (lane == 0) lam[base + j] = dorg + tau;
