@@ -250,8 +250,9 @@ def main():
         roof = max(crit or cands, key=lambda c: c["total_ms_per_fit"]) if cands else None
         tu_ms, tu_flops, tu_n = prof["trailing_update"]
         res = {
-            "metric": "bigKRLS_fit_wall_clock_s (full fit, N=20000, P=20, fp64)" if (n, p) == (20000, 20)
-                      else f"bigKRLS_fit_wall_clock_s (full fit, N={n}, P={p}, fp64)",
+            # BASELINE.json: "bigKRLS() fit wall-clock + kernel-GEMM fp64 GFLOP/s at N=20000,P=20";
+            # `value` is the wall-clock half, `kernel_gemm.gflops` the GEMM half
+            "metric": f"bigKRLS() fit wall-clock at N={n},P={p} (kernel-GEMM fp64 GFLOP/s in kernel_gemm.gflops)",
             "value": round(sec_per_fit, 4),
             "unit": "s",
             "n_gpus": world,
@@ -270,13 +271,15 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"row-block x{world}, RCCL all-gather"},
             "phases_s": phases,
             "kernel_gemm": {
+                "gflops": round(kb_flops / (kb_ms / 1e3) / 1e9, 1) if kb_ms > 0 else None,
                 "tflops": round(kb_flops / (kb_ms / 1e3) / 1e12, 3) if kb_ms > 0 else None,
                 "frac_of_fp64_mfma_peak": round(kb_flops / (kb_ms / 1e3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if kb_ms > 0 else None,
                 "hbm_write_gbs": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3), 1) if kb_ms > 0 else None,
                 "frac_of_hbm_peak": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3) / HBM_PEAK_GBS, 4) if kb_ms > 0 else None,
                 "ms": round(kb_ms / max(kb_n, 1), 4), "launches": kb_n,
-                "note": "kernel_block_wave_kernel: 2*N^2*P flops per launch; at P=20 the build is HBM-write "
-                        "bound (8 N^2 bytes, AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
+                "note": "kernel_block_sym_kernel: 2*N^2*P algorithmic flops per launch (the symmetric variant "
+                        "executes half of them and mirrors); at P=20 the build is HBM-write bound (8 N^2 bytes, "
+                        "AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
             "roofline": roof,
             "other_kernels": [c for c in cands if c is not roof],
         }
