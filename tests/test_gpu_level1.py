@@ -275,3 +275,40 @@ def test_eigen_two_stage_kernel_variants(lib, monkeypatch, bc, pq, n):
     assert np.max(np.abs(vals - ref_vals)) / scale < 1e-12
     assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-11
     assert np.max(np.abs(K @ vecs - vecs * vals)) / scale < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["graded", "clusters", "identity", "rank3", "wilkinson", "negdef"])
+@pytest.mark.parametrize("n", [300, 777])
+def test_eigen_hard_spectra(lib, kind, n):
+    """Spectra that break naive divide & conquer / secular solvers (tight clusters, 16 orders of
+    grading, heavy deflation, Wilkinson's matrix, indefinite input): eigenvalues vs LAPACK,
+    orthogonality and residuals at rounding level."""
+    rng = np.random.default_rng(n)
+
+    def with_spectrum(d):
+        Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        return (Qm * d) @ Qm.T
+
+    if kind == "graded":
+        A = with_spectrum(np.logspace(0, -16, n))
+    elif kind == "clusters":
+        A = with_spectrum(np.r_[1 + 1e-13 * rng.standard_normal(n // 2), 2 + 1e-13 * rng.standard_normal(n - n // 2)])
+    elif kind == "identity":
+        A = np.eye(n)
+    elif kind == "rank3":
+        A = with_spectrum(np.r_[[5.0, 3.0, 1.0], 1e-14 * rng.random(n - 3)])
+    elif kind == "wilkinson":
+        A = np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    else:
+        A = -with_spectrum(np.logspace(0, -10, n))
+    A = (A + A.T) / 2
+    vals = np.zeros(n)
+    vecs = F(np.zeros((n, n)))
+    Af = F(A)
+    check(lib, lib.bigkrls_eigen(P(Af), n, n, P(vals), P(vecs)))
+    ref = np.linalg.eigvalsh(A)[::-1]
+    scale = max(np.abs(ref).max(), 1e-300)
+    assert np.max(np.abs(vals - ref)) / scale < 1e-12
+    assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-11
+    assert np.max(np.abs(A @ vecs - vecs * vals)) / scale < 1e-11
