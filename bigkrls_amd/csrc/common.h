@@ -94,6 +94,11 @@ enum Slot {
   SLOT_EIG_Z = 19,
   SLOT_EIG_DESC = 20,
   SLOT_EIG_VV = 21,
+  SLOT_KRY_B = 22,
+  SLOT_KRY_W = 23,
+  SLOT_KRY_C = 24,
+  SLOT_KRY_T = 25,
+  SLOT_KRY_Y = 26,
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

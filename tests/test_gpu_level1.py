@@ -312,3 +312,32 @@ def test_eigen_hard_spectra(lib, kind, n):
     assert np.max(np.abs(vals - ref)) / scale < 1e-12
     assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-11
     assert np.max(np.abs(A @ vecs - vecs * vals)) / scale < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p,neig,trunc", [(4608, 6, 128, 0.0), (5000, 10, 300, 0.001)])
+def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, neig, trunc):
+    """Neig << N (the reference's eigs_sym branch, src/eigen.cpp:18-22): the block-Lanczos path
+    (forced here; by default it takes over at N >= 16384, Neig <= N/8) against the dense path of
+    the same library and against ARPACK (the oracle's stand-in for eigs_sym)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    ctx = bk.Context(0)
+    X, y = orc.synth(n, p, 31)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    monkeypatch.setenv("BIGKRLS_EIGK", "dense")
+    d = ops.bEigen(K, neig, trunc)
+    monkeypatch.setenv("BIGKRLS_EIGK", "krylov")
+    a = ops.bEigen(K, neig, trunc)
+    assert a.lastkeeper == d.lastkeeper
+    assert np.max(np.abs(a.values - d.values)) <= 1e-11 * d.values[0]
+    Qa, Qd = a.vectors.to_numpy(), d.vectors.to_numpy()
+    assert np.max(np.abs(Qa.T @ Qa - np.eye(Qa.shape[1]))) < 1e-11
+    ys = (y - y.mean()) / y.std(ddof=1)
+    w = 1.0 / (d.values[:d.lastkeeper] + 0.5)
+    cd, ca = Qd @ (w * (Qd.T @ ys)), Qa @ (w * (Qa.T @ ys))       # rotation/sign invariant
+    assert np.max(np.abs(cd - ca)) <= 1e-8 * np.max(np.abs(cd))
+    ref = orc.b_eigen(K.to_numpy(), neig, trunc)                   # ARPACK
+    assert ref.lastkeeper == a.lastkeeper
+    assert np.max(np.abs(a.values - ref.values)) <= 1e-9 * ref.values[0]
