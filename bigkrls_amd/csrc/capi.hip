@@ -85,6 +85,7 @@ int side_stream_get(bigkrls_ctx* ctx) {
     BK_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    BK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
   }
   return BIGKRLS_OK;
 }
@@ -262,6 +263,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return BIGKRLS_OK;

@@ -53,7 +53,7 @@ struct bigkrls_ctx {
   std::vector<const void*> dyn_smem_done;
   std::vector<std::pair<const void*, int>> resident_cap;
   hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
   static constexpr int kSlots = 32;
   void* ws[kSlots] = {nullptr};
@@ -99,6 +99,7 @@ enum Slot {
   SLOT_KRY_C = 24,
   SLOT_KRY_T = 25,
   SLOT_KRY_Y = 26,
+  SLOT_SIDE_SPLITK = 27,   // split-K partials of GEMMs issued on the look-ahead stream
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

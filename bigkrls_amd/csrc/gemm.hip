@@ -394,7 +394,9 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
   double* partial = nullptr;
   if (splits > 1) {
     void* p = nullptr;
-    BK_TRY(ws_get(ctx, SLOT_GEMM_SPLITK, (int64_t)splits * g.M * g.N * sizeof(double), &p));
+    // GEMMs issued on the look-ahead stream run concurrently with main-stream GEMMs: own partial buffer
+    const int slot = (ctx->side_stream && ctx->stream == ctx->side_stream) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
+    BK_TRY(ws_get(ctx, slot, (int64_t)splits * g.M * g.N * sizeof(double), &p));
     partial = (double*)p;
   }
   auto kern = gemm_kernel<TA, TB, BN>;
