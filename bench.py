@@ -58,6 +58,16 @@ def symv_traffic(alg_bytes_total, launches):
     return round(alg_bytes_total / launches * ratio, 0)
 
 
+def pmc_ratio(kernel):
+    """traffic / algorithmic HBM bytes of a kernel from the rocprofv3 PMC passes in
+    profiles/r01_traffic_pmc.json (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated there)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    try:
+        return float(json.load(open(path))[kernel]["traffic_over_algorithmic"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(p, n_cpu, seed):
     """Literal CPU restatement (oracle, kind 'port') of the same fit on a bounded sample."""
     import numpy as np
@@ -155,13 +165,14 @@ def main():
 
         STRIDE = 4   # the library brackets every 4th stage-1 panel (S1_PROF_STRIDE): totals are x4
 
-        def mfma_entry(name, kernel, note):
+        def mfma_entry(name, kernel, note, traffic=None):
             ms, fl, cnt = prof[name]
             if ms <= 0:
                 return None
             tf = fl / (ms / 1e3) / 1e12
             return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic(fl / max(cnt, 1)) if traffic else None,
                     "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
                     "total_ms_per_fit": round(ms * STRIDE / args.steps, 2),
                     "avg_algorithmic_flops_per_launch": round(fl / max(cnt, 1), 0),
@@ -238,7 +249,11 @@ def main():
             mfma_entry("band_update", "syrk_mirror_kernel: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
                        "store (stage 1 of the two-stage tridiagonalisation), one launch per 64-column panel",
                        "achieved = m(m+1)*2b algorithmic flops per launch (lower triangle incl. diagonal tiles, "
-                       "m = trailing size, b = 64) / HIP-event duration on the launch stream"),
+                       "m = trailing size, b = 64) / HIP-event duration on the launch stream; traffic = algorithmic "
+                       "HBM bytes of the launch (read 4 m^2 + write 8 m^2) x the FETCH_SIZE+WRITE_SIZE / algorithmic "
+                       "ratio of profiles/r01_traffic_pmc.json (1.011)",
+                       traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel"), 0))
+                       if pmc_ratio("syrk_mirror_kernel") else None),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
                        "achieved = 2 m^2 b flops per launch / HIP-event duration"),
         ]
@@ -277,6 +292,8 @@ def main():
                 "hbm_write_gbs": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3), 1) if kb_ms > 0 else None,
                 "frac_of_hbm_peak": round(8.0 * (kb_flops / (2.0 * p)) / 1e9 / (kb_ms / 1e3) / HBM_PEAK_GBS, 4) if kb_ms > 0 else None,
                 "ms": round(kb_ms / max(kb_n, 1), 4), "launches": kb_n,
+                "traffic": (round(8.0 * n * n * pmc_ratio("kernel_block_sym_kernel"), 0)
+                            if pmc_ratio("kernel_block_sym_kernel") else None),
                 "note": "kernel_block_sym_kernel: 2*N^2*P algorithmic flops per launch (the symmetric variant "
                         "executes half of them and mirrors); at P=20 the build is HBM-write bound (8 N^2 bytes, "
                         "AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},

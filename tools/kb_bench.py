@@ -1,5 +1,6 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bigkrls_amd as bk
 from bigkrls_amd import ops
 n, p = int(sys.argv[1]), int(sys.argv[2])
