@@ -6,7 +6,9 @@ symmetric, so the row block is stored as the contiguous column block K[:, r0:r1]
 
   phase            local work                         exchange
   kernel build     K[:, r0:r1] (fp64 MFMA + exp)       all-gather of the column blocks
-  eigen            reduction + divide&conquer          all-reduce (sum) of Q: every rank
+  eigen (Neig<<N)  block Lanczos: rows r0:r1 of K B_j   all-gather of an N x 128 block per step;
+                   (K never leaves its row blocks)      orthogonalisation / Ritz problem replicated
+  eigen (dense)    reduction + divide&conquer          all-reduce (sum) of Q: every rank
                    replicated (not yet distributed     back-transforms its own slice of the
                    -- section 8(f))                     eigenvector columns, zeros elsewhere
   lambda search    Q[r0:r1,:]: a_r = Q_r' y_r          all-reduce a (K doubles) once,
@@ -25,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
 from typing import Dict, Optional
 
@@ -130,6 +133,27 @@ class HipBackend:
                   C.c_void_p(S.data_ptr()), p, n, C.c_void_p(sc.ctypes.data), C.c_void_p(var.ctypes.data))
         return var
 
+    def mm(self, ta, tb, A, B, alpha=1.0, beta=0.0, out=None):
+        """out = alpha op(A) op(B) + beta out on column-major matrices held as (ncol, nrow) tensors."""
+        # a (ncol, nrow) tensor is the column-major nrow x ncol matrix: rows = shape[1], cols = shape[0]
+        am, ak = (A.shape[0], A.shape[1]) if ta else (A.shape[1], A.shape[0])
+        bk2, bn = (B.shape[1], B.shape[0]) if not tb else (B.shape[0], B.shape[1])
+        assert ak == bk2, (A.shape, B.shape, ta, tb)
+        assert A.is_contiguous() and B.is_contiguous()
+        if out is None:
+            out = self.torch.empty((bn, am), dtype=self.torch.float64, device=self.device)
+        assert out.shape == (bn, am) and out.is_contiguous()
+        _lib.call("bigkrls_dev_gemm", self.ctx.handle, int(ta), int(tb), am, bn, ak, float(alpha),
+                  C.c_void_p(A.data_ptr()), A.shape[1], C.c_void_p(B.data_ptr()), B.shape[1], float(beta),
+                  C.c_void_p(out.data_ptr()), out.shape[1])
+        return out
+
+    def dense_eig_top(self, T, k):
+        """All eigenvalues (descending, host) and the top-k eigenvectors (tensor (k, m)) of the dense
+        symmetric T given as a host array."""
+        eo = ops.bEigen(self.ctx.from_numpy(np.asfortranarray(T)), T.shape[0], -1.0)
+        return eo.values, eo.vectors.t[:k]
+
     def sync(self):
         self.ctx.sync()
 
@@ -155,13 +179,153 @@ def _all_gather_vec(torch, dist, local, nb, n_total, world):
     return full.permute(1, 0, 2).reshape(rows, world * nb)[:, :n_total].contiguous()
 
 
+def _chol_upper_and_inverse(G):
+    """Upper Cholesky factor R (G = R'R) and R^-1 of a small SPD matrix with plain numpy vector
+    operations. (A threaded LAPACK call on a 128 x 128 matrix costs ~10 ms on a 128-core host,
+    which would dominate a Lanczos step.) Returns (None, None) on breakdown."""
+    b = G.shape[0]
+    R = np.zeros((b, b))
+    A = G.copy()
+    for j in range(b):
+        d = A[j, j]
+        if not (d > 0.0) or not np.isfinite(d):
+            return None, None
+        rjj = math.sqrt(d)
+        R[j, j] = rjj
+        if j + 1 < b:
+            row = A[j, j + 1:] / rjj
+            R[j, j + 1:] = row
+            A[j + 1:, j + 1:] -= np.outer(row, row)
+    Rinv = np.zeros((b, b))
+    eye = np.eye(b)
+    for i in range(b - 1, -1, -1):             # row i of R^-1 from the rows below it (R Rinv = I)
+        Rinv[i, :] = (eye[i, :] - R[i, i + 1:] @ Rinv[i + 1:, :]) / R[i, i]
+    return R, Rinv
+
+
+def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrunc, block=128, tol=1e-10,
+                      seed=20240229):
+    """Top-`neig` eigenpairs of K for Neig << N without ever forming K on one GPU (SURVEY 8(e),
+    "Eigen, partial"): block Lanczos with full re-orthogonalisation, the K B_j products sharded by
+    row block -- rank r multiplies its own rows K[r0:r1, :] (stored as the column block
+    Kcols = K[:, r0:r1]) and one all-gather of an N x 128 block per step assembles K B_j; the
+    orthogonalisation, the Cholesky QR and the projected eigenproblem are replicated (identical,
+    deterministic arithmetic on every rank). Same algorithm and stopping rule as the single-GPU
+    `eigen_krylov` in csrc/eigen.hip. Returns (values[neig] host, lastkeeper, Q tensor (lastkeeper, n),
+    values tensor (1, neig))."""
+    b = int(block)
+    nb, parts = partition(n, world)
+    r0, r1 = parts[rank]
+    maxdim = min(n // 2 // b * b, max(16 * neig, 4096) // b * b)
+    maxsteps = maxdim // b
+
+    def k_times(Bj):                       # (b, n) tensor == n x b column-major  ->  K Bj, same layout
+        cols = Bj.shape[0]
+        Wloc = torch.zeros((cols, nb), dtype=torch.float64, device=Bj.device)
+        if r1 > r0:
+            Wloc[:, : r1 - r0] = backend.mm(True, False, Kcols, Bj)     # (K[:, r0:r1])' Bj  = rows r0:r1 of K Bj
+        if world == 1:
+            return Wloc[:, :n].contiguous()
+        full = torch.empty((world * cols, nb), dtype=torch.float64, device=Bj.device)
+        dist.all_gather_into_tensor(full, Wloc.contiguous())
+        return full.view(world, cols, nb).permute(1, 0, 2).reshape(cols, world * nb)[:, :n].contiguous()
+
+    def cholqr2(W):
+        """Orthonormalise the columns of W (tensor (b, n)); returns (Q, R host upper, ok)."""
+        Racc = None
+        for _ in range(2):
+            G = backend.mm(True, False, W, W).cpu().numpy().T       # b x b
+            G = 0.5 * (G + G.T)
+            R, Rinv = _chol_upper_and_inverse(G)                     # G = R'R (no threaded LAPACK: b is 128)
+            if R is None:
+                return W, None, False
+            W = backend.mm(False, False, W, backend.from_numpy(Rinv))
+            Racc = R if Racc is None else R @ Racc
+        return W, Racc, True
+
+    import time as _t
+    _prof = {} if os.environ.get("BIGKRLS_VERBOSE") else None
+
+    def _tick(name, t0):
+        if _prof is not None:
+            backend.sync()
+            _prof[name] = _prof.get(name, 0.0) + (_t.perf_counter() - t0)
+
+    rng = np.random.default_rng(seed)
+    W0 = backend.from_numpy(rng.random((n, b)) - 0.5)
+    Bj, _, ok = cholqr2(W0)
+    if not ok:
+        raise RuntimeError("eigen_krylov_dist: start block is rank deficient")
+    Ball = torch.empty((maxdim, n), dtype=torch.float64, device=Bj.device)
+    Ball[:b] = Bj
+    Ablk, Bblk = [], []
+    steps, converged, Y, theta = 0, False, None, None
+    next_check = max(2, (4 * neig + b - 1) // b)
+    while True:
+        _t0 = _t.perf_counter()
+        W = k_times(Ball[steps * b:(steps + 1) * b])
+        _tick("K*B", _t0); _t0 = _t.perf_counter()
+        dim = (steps + 1) * b
+        Bv = Ball[:dim]
+        Aj = None
+        for pas in range(2):                                          # classical Gram-Schmidt, twice
+            Cc = backend.mm(True, False, Bv, W)                       # dim x b
+            if pas == 0:
+                Aj = Cc[:, steps * b:(steps + 1) * b].cpu().numpy().T.copy()
+            W = backend.mm(False, False, Bv, Cc, alpha=-1.0, beta=1.0, out=W)
+        _tick("cgs2", _t0); _t0 = _t.perf_counter()
+        W, R, ok = cholqr2(W)
+        _tick("cholqr2", _t0); _t0 = _t.perf_counter()
+        Ablk.append(0.5 * (Aj + Aj.T))
+        steps += 1
+        last = (not ok) or steps >= maxsteps
+        if ok:
+            Bblk.append(R)
+        if last or steps >= next_check:
+            m = steps * b
+            T = np.zeros((m, m))
+            for j in range(steps):
+                T[j * b:(j + 1) * b, j * b:(j + 1) * b] = Ablk[j]
+                if j + 1 < steps:
+                    T[(j + 1) * b:(j + 2) * b, j * b:(j + 1) * b] = Bblk[j]
+                    T[j * b:(j + 1) * b, (j + 1) * b:(j + 2) * b] = Bblk[j].T
+            theta, Y = backend.dense_eig_top(T, neig)                 # Y: (neig, m)
+            worst = 0.0
+            if ok:
+                Ylast = Y[:, m - b:].cpu().numpy().T                  # b x neig
+                worst = float(np.max(np.linalg.norm(Bblk[-1] @ Ylast, axis=0)))
+            if worst <= tol * abs(theta[0]) or last:
+                converged = worst <= tol * abs(theta[0])
+                break
+            next_check = steps + max(2, steps // 6)
+            _tick("check", _t0); _t0 = _t.perf_counter()
+        Ball[steps * b:(steps + 1) * b] = W
+    if not converged:
+        raise RuntimeError("eigen_krylov_dist: not converged within the subspace limit")
+    dim = steps * b
+    Q = backend.mm(False, False, Ball[:dim], Y)                       # n x neig
+    KQ = k_times(Q)
+    H = backend.mm(True, False, Q, KQ).cpu().numpy().T
+    H = 0.5 * (H + H.T)
+    hv, Zr = backend.dense_eig_top(H, neig)
+    vals = np.asarray(hv[:neig], dtype=np.float64)
+    lastkeeper = int(np.max(np.nonzero(vals >= eigtrunc * vals[0])[0])) + 1
+    Qf = backend.mm(False, False, Q, Zr[:lastkeeper])
+    if _prof is not None and rank == 0:
+        print("[bigkrls] eigen_krylov_dist steps=%d dim=%d" % (steps, dim), {kk: round(v, 3) for kk, v in _prof.items()}, flush=True)
+    return vals, lastkeeper, Qf, backend.from_numpy(vals[:, None])
+
+
 def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig=None, eigtrunc=None,
                  lambda_=None, L=None, U=None, ctx: Optional[Context] = None, backend=None,
-                 timings: Optional[Dict[str, float]] = None, trace=None, keep_outputs=True) -> BigKRLS:
+                 timings: Optional[Dict[str, float]] = None, trace=None, keep_outputs=True,
+                 eigen_mode: Optional[str] = None) -> BigKRLS:
     """bigKRLS() with the kernel build, lambda search, coefficient, variance and
     marginal-effects passes partitioned over the ranks of the default process group.
     Every rank returns the same small outputs; N x N outputs stay sharded
-    (`K.cols`, `vcov.est.c.cols`, `vcov.est.fitted.cols` hold this rank's column block)."""
+    (`K.cols`, `vcov.est.c.cols`, `vcov.est.fitted.cols` hold this rank's column block).
+    `eigen_mode`: None (block Lanczos with sharded products when N >= 16384 and Neig <= N/8, like
+    the single-GPU library), "krylov" or "dense" to force either."""
     import torch
     import torch.distributed as dist
 
@@ -204,18 +368,29 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     if r1 > r0:
         backend.kernel_cols(Xd, sigma, r0, r1, Kloc)
     mark("kernel")
-    if world > 1:
-        dist.all_gather_into_tensor(Kpad, Kpad[rank * nb:(rank + 1) * nb].clone())
-    K = Kpad[:n]
-    Kcols = K[r0:r1]
-    mark("kernel_allgather")
-    # ---- step 2: eigen (replicated) -------------------------------------------------
-    vals, lastkeeper, Q, dvals = backend.eigen(K, Neig, eigtrunc, rank, world)
-    if world > 1:
-        # each rank back-transformed its own eigenvector columns (zeros elsewhere): sum = Q.
-        # This is the RCCL exchange north_star names for the eigenvector back-transform.
-        dist.all_reduce(Q, op=dist.ReduceOp.SUM)
-    mark("eigen")
+    Neig_eff = n if Neig is None else min(int(Neig), n)
+    use_krylov = (eigen_mode == "krylov") or (eigen_mode is None and Neig_eff * 8 <= n and n >= 16384)
+    if use_krylov:
+        # Neig << N: K stays sharded (no all-gather of K); block Lanczos with sharded K B_j products
+        Kcols = Kloc
+        mark("kernel_allgather")
+        vals, lastkeeper, Q, dvals = eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, Neig_eff,
+                                                       eigtrunc)
+        K = None
+        mark("eigen")
+    else:
+        if world > 1:
+            dist.all_gather_into_tensor(Kpad, Kpad[rank * nb:(rank + 1) * nb].clone())
+        K = Kpad[:n]
+        Kcols = K[r0:r1]
+        mark("kernel_allgather")
+        # ---- step 2: eigen (replicated) -------------------------------------------------
+        vals, lastkeeper, Q, dvals = backend.eigen(K, Neig, eigtrunc, rank, world)
+        if world > 1:
+            # each rank back-transformed its own eigenvector columns (zeros elsewhere): sum = Q.
+            # This is the RCCL exchange north_star names for the eigenvector back-transform.
+            dist.all_reduce(Q, op=dist.ReduceOp.SUM)
+        mark("eigen")
     # ---- step 3: lambda search on row blocks of Q ------------------------------------
     a = backend.qty_rows(Q, r0, r1, yd)
     if world > 1:

@@ -28,3 +28,17 @@ def test_row_block_fit_matches_oracle(world, n, p, binary):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("OK") == world
+
+
+@pytest.mark.parametrize("world,n,p,neig", [(2, 1100, 3, 12), (3, 900, 2, 8)])
+def test_sharded_block_lanczos_matches_lapack(world, n, p, neig):
+    """SURVEY 8(e) "Eigen, partial": rank r multiplies its own rows of K, one all-gather of an
+    N x block matrix per Lanczos step; everything else replicated."""
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "_dist_worker.py"), "krylov", str(n), str(p), str(neig)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == world

@@ -283,3 +283,20 @@ def test_eigen_column_partition_sums_to_full():
         assert not Qp[:, :c0].any() and not Qp[:, c1:].any()
         acc += Qp
     assert np.array_equal(acc, Qf)
+
+
+@pytest.mark.gpu
+def test_dist_path_sharded_block_lanczos_world1(ctx):
+    """The row-sharded block-Lanczos eigen path of bigkrls_amd.dist (SURVEY 8(e) "Eigen, partial") with
+    the HIP backend on one GPU: same fit as the single-GPU library (which runs its own C++ block
+    Lanczos or the dense path) for Neig << N."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import dist as bkdist
+    X, y = orc.synth(4500, 6, 52)
+    one = bk.bigKRLS(y, X, Neig=96, ctx=ctx)
+    out = bkdist.bigKRLS_dist(y, X, Neig=96, ctx=ctx, eigen_mode="krylov")
+    assert out["lastkeeper"] == one["lastkeeper"]
+    assert abs(out["lambda"] - one["lambda"]) <= 1e-8 * one["lambda"]
+    assert rel(out["K.eigenvalues"], one["K.eigenvalues"]) < 1e-9
+    for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives"):
+        assert rel(out[k], one[k]) < TOL, k
