@@ -163,7 +163,7 @@ def main():
         phases = {k: round(v / args.steps, 4) for k, v in phase_sum.items()}
         kb_ms, kb_flops, kb_n = prof["kernel_block"]
 
-        STRIDE = 4   # the library brackets every 4th stage-1 panel (S1_PROF_STRIDE): totals are x4
+        STRIDE = 8   # the library brackets every 8th stage-1 panel (S1_PROF_STRIDE): totals are x8
 
         def mfma_entry(name, kernel, note, traffic=None):
             ms, fl, cnt = prof[name]
@@ -176,7 +176,7 @@ def main():
                     "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
                     "total_ms_per_fit": round(ms * STRIDE / args.steps, 2),
                     "avg_algorithmic_flops_per_launch": round(fl / max(cnt, 1), 0),
-                    "note": note + "; every 4th panel is bracketed (total_ms_per_fit = 4 x the sampled time)"}
+                    "note": note + "; every 8th panel is bracketed (total_ms_per_fit = 8 x the sampled time)"}
 
         def symv_entry():
             ms, by, cnt = prof["symv"]

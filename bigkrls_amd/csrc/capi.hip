@@ -101,8 +101,13 @@ static bigkrls_ctx::ProfEntry* prof_entry(bigkrls_ctx* ctx, const char* name) {
 int prof_begin(bigkrls_ctx* ctx, const char* name, double work, hipStream_t stream) {
   if (!ctx->profile) return BIGKRLS_OK;
   bigkrls_ctx::ProfSample s{};
-  BK_HIP(hipEventCreate(&s.e0));
-  BK_HIP(hipEventCreate(&s.e1));
+  auto take = [&](hipEvent_t* e) -> int {
+    if (!ctx->prof_pool.empty()) { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return BIGKRLS_OK; }
+    BK_HIP(hipEventCreate(e));
+    return BIGKRLS_OK;
+  };
+  BK_TRY(take(&s.e0));
+  BK_TRY(take(&s.e1));
   s.work = work;
   BK_HIP(hipEventRecord(s.e0, stream ? stream : ctx->stream));
   prof_entry(ctx, name)->pending.push_back(s);
@@ -127,8 +132,8 @@ static int prof_flush(bigkrls_ctx* ctx) {
       e.ms += ms;
       e.work += s.work;
       e.launches += 1;
-      (void)hipEventDestroy(s.e0);
-      (void)hipEventDestroy(s.e1);
+      ctx->prof_pool.push_back(s.e0);
+      ctx->prof_pool.push_back(s.e1);
     }
     e.pending.clear();
   }
@@ -260,6 +265,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)bigkrls_ctx_release_workspace(ctx);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

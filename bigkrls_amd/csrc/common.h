@@ -66,6 +66,7 @@ struct bigkrls_ctx {
   struct ProfSample { hipEvent_t e0, e1; double work; };
   struct ProfEntry { std::string name; std::vector<ProfSample> pending; double ms = 0, work = 0; int64_t launches = 0; };
   std::vector<ProfEntry> prof;
+  std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per sample costs more than the sample)
 };
 
 namespace bk {
