@@ -25,6 +25,17 @@
  *
  * There is no CPU fallback: without a HIP device every compute entry point
  * returns BIGKRLS_ENODEVICE.
+ *
+ * Threading: a bigkrls_ctx (its stream, its look-ahead stream and its reusable
+ * workspace) serves one host thread at a time -- the reference's native code is
+ * single-threaded too (one PSOCK worker process per concurrent call,
+ * R/bigKRLS.R:345-362); use one context per thread / per GPU. The Level-1 entry
+ * points share one default context behind a mutex-protected creation and must not
+ * be called concurrently. bigkrls_last_error() is per thread.
+ * The eigensolver's persistent kernels spin on messages from other workgroups;
+ * they are launched with grids no larger than the co-resident capacity of the
+ * device and every wait is bounded: a violated assumption surfaces as BIGKRLS_EHIP
+ * (message names the fallback switches BIGKRLS_BC / BIGKRLS_PQ), never as a hang.
  */
 #ifndef BIGKRLS_H
 #define BIGKRLS_H
