@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
   timeit("gemm NT m=n=n k=128 beta=1", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 1.0, C, n); });
   timeit("gemm NT m=n=n k=128 beta=0", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 0.0, C, n); });
   timeit("gemm NN (n x 64) = C(n x n) * A(n x 64)", 2.0 * n * n * 64, [&] { gemm(ctx, 0, 0, n, 64, n, 1.0, C, n, A, n, 0.0, B, n); });
+  timeit("gemm NT (n x 64) = C(n x n) * At(64 x n)'", 2.0 * n * n * 64, [&] { gemm(ctx, 0, 1, n, 64, n, 1.0, C, n, A, 64, 0.0, B, n); });
   const int64_t q = 8192;
   if (n * n < 3 * q * q) return 0;
   timeit("gemm NN 8192^3", 2.0 * q * q * q, [&] { gemm(ctx, 0, 0, q, q, q, 1.0, C, q, C + q * q, q, 0.0, C + 2 * q * q, q); });
