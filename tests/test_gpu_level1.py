@@ -29,7 +29,7 @@ def check(lib, status):
     assert status == 0, lib.bigkrls_last_error().decode()
 
 
-@pytest.mark.parametrize("n,p", [(1, 1), (7, 3), (129, 5), (500, 5), (1000, 20), (777, 50)])
+@pytest.mark.parametrize("n,p", [(1, 1), (7, 3), (129, 5), (500, 5), (1000, 20), (777, 50), (300, 150), (513, 129)])
 def test_gauss_kernel(lib, n, p):
     X, y = orc.synth(n, p, 1)
     if n > 1:
@@ -64,7 +64,7 @@ def test_gauss_kernel_mtcars_golden(lib):
     assert np.abs(diff).max() < 1e-12           # and what it actually achieves
 
 
-@pytest.mark.parametrize("u,v,p", [(1, 1, 1), (50, 500, 5), (333, 129, 20), (130, 260, 3)])
+@pytest.mark.parametrize("u,v,p", [(1, 1, 1), (50, 500, 5), (333, 129, 20), (130, 260, 3), (200, 77, 140)])
 def test_temp_kernel(lib, u, v, p):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((u, p))
