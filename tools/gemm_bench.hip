@@ -3,6 +3,7 @@
 #include "../bigkrls_amd/csrc/common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 using namespace bk;
 __global__ void fillr(double* p, int64_t n, unsigned seed) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -34,6 +35,25 @@ int main(int argc, char** argv) {
   timeit("gemm NT m=n=n k=128 beta=0", 2.0 * n * n * 128, [&] { gemm(ctx, 0, 1, n, n, 128, -1.0, A, n, B, n, 0.0, C, n); });
   timeit("gemm NN (n x 64) = C(n x n) * A(n x 64)", 2.0 * n * n * 64, [&] { gemm(ctx, 0, 0, n, 64, n, 1.0, C, n, A, n, 0.0, B, n); });
   timeit("gemm NT (n x 64) = C(n x n) * At(64 x n)'", 2.0 * n * n * 64, [&] { gemm(ctx, 0, 1, n, 64, n, 1.0, C, n, A, 64, 0.0, B, n); });
+  {
+    // concurrency probe: trailing update and the A22 V product on two streams at once vs back to back
+    bigkrls_ctx* ctx2; bigkrls_ctx_create(0, &ctx2);
+    double* C2; hipMalloc(&C2, n * n * 8); hipMemcpy(C2, C, n * n * 8, hipMemcpyDeviceToDevice);
+    double* Y; hipMalloc(&Y, n * 64 * 8);
+    auto wall = [&](const char* name, auto fn) {
+      fn(); hipDeviceSynchronize();
+      auto t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < 3; ++r) fn();
+      hipDeviceSynchronize();
+      double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 3;
+      printf("%-44s %9.1f us\n", name, us);
+    };
+    wall("syrk_mirror<64> alone", [&] { syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, -1, true); });
+    wall("A22 V alone (other buffer)", [&] { gemm(ctx2, 0, 0, n, 64, n, 1.0, C2, n, A, n, 0.0, Y, n); });
+    wall("syrk_mirror<64> || A22 V (two streams)", [&] {
+      syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, -1, true);
+      gemm(ctx2, 0, 0, n, 64, n, 1.0, C2, n, A, n, 0.0, Y, n); });
+  }
   const int64_t q = 8192;
   if (n * n < 3 * q * q) return 0;
   timeit("gemm NN 8192^3", 2.0 * q * q * q, [&] { gemm(ctx, 0, 0, q, q, q, 1.0, C, q, C + q * q, q, 0.0, C + 2 * q * q, q); });
