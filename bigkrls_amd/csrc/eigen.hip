@@ -1278,6 +1278,8 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
   void* pY = nullptr;
   bool converged = false;
   int next_check = (int)std::max<int64_t>(2, (4 * k + b - 1) / b);   // each check is a dense eigensolve of T
+  double prev_worst = -1.0;
+  int prev_steps = 0;
   while (true) {
     // ---- one block Lanczos step: W = K B_j, orthogonalised against every block so far (CGS2) ---
     const double* Bj = B + (int64_t)steps * b * n;
@@ -1349,7 +1351,17 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
         dim = m;
         break;
       }
-      next_check = steps + std::max(2, steps / 6);
+      // Next check: the worst residual decays geometrically with the number of steps, so two checks
+      // predict where it crosses the tolerance (each check costs a dense eigensolve of T).
+      int inc = std::max(2, steps / 6);
+      if (prev_worst > 0.0 && worst > 0.0 && worst < prev_worst) {
+        const double rate = std::log(worst / prev_worst) / (double)(steps - prev_steps);   // < 0 per step
+        const double need = std::log(tol * std::fabs(theta[0]) / worst) / rate;
+        if (std::isfinite(need) && need > 0.0) inc = std::max(1, std::min((int)std::ceil(need) + 1, 4 * inc));
+      }
+      prev_worst = worst;
+      prev_steps = steps;
+      next_check = steps + inc;
     }
     BK_HIP(hipMemcpyAsync(B + (int64_t)steps * b * n, W, n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
     dim = (int64_t)(steps + 1) * b;

@@ -261,6 +261,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     Ablk, Bblk = [], []
     steps, converged, Y, theta = 0, False, None, None
     next_check = max(2, (4 * neig + b - 1) // b)
+    prev_worst, prev_steps = -1.0, 0
     while True:
         _t0 = _t.perf_counter()
         W = k_times(Ball[steps * b:(steps + 1) * b])
@@ -297,7 +298,14 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             if worst <= tol * abs(theta[0]) or last:
                 converged = worst <= tol * abs(theta[0])
                 break
-            next_check = steps + max(2, steps // 6)
+            inc = max(2, steps // 6)                                 # same schedule as csrc/eigen.hip
+            if prev_worst > 0.0 and 0.0 < worst < prev_worst:
+                rate = math.log(worst / prev_worst) / (steps - prev_steps)
+                need = math.log(tol * abs(theta[0]) / worst) / rate
+                if math.isfinite(need) and need > 0.0:
+                    inc = max(1, min(int(math.ceil(need)) + 1, 4 * inc))
+            prev_worst, prev_steps = worst, steps
+            next_check = steps + inc
             _tick("check", _t0); _t0 = _t.perf_counter()
         Ball[steps * b:(steps + 1) * b] = W
     if not converged:
