@@ -241,6 +241,7 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     T["wall"] = time.perf_counter() - t_wall0
     for i, nm in enumerate(names):
         T[nm] = Context.elapsed_ms(ev[i], ev[i + 1]) / 1e3
+    ctx.release_events(ev)
     w["_ctx"] = ctx
     return w
 

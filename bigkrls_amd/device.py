@@ -14,6 +14,44 @@ import numpy as np
 
 from . import _lib
 
+# Host <-> HBM transfers go through a pinned staging buffer owned by the context, never through
+# the caller's pageable memory: for copies above ~1 MB the HIP runtime pins the user pages in
+# place, and when numpy later unmaps that memory (free of a multi-MB array) the kernel driver
+# evicts and restores the process's GPU queues -- measured as sporadic 50-100 ms stalls at the
+# first synchronisation of the next fit (tools/pending_probe.py).
+_STAGE_MIN = 1 << 20     # doubles (8 MB)
+_STAGE_MAX = 1 << 24     # doubles (128 MB): larger transfers are pipelined through two halves
+
+
+def _column_major_filler(a: np.ndarray):
+    """fill(dst, off, m): write elements [off, off+m) of the column-major flattening of the 2-D
+    array `a` into `dst`, without a full-size temporary whatever the layout of `a`."""
+    nrow = a.shape[0]
+    if a.flags.f_contiguous:
+        src = a.reshape(-1, order="F")          # a view: already in column-major order
+
+        def fill(dst, off, m):
+            dst[:] = src[off:off + m]
+        return fill
+
+    def fill(dst, off, m):                      # whole and partial columns of the piece
+        c0, r0 = divmod(off, nrow)
+        pos = 0
+        while pos < m:
+            take = min(nrow - r0, m - pos)
+            if r0 == 0 and take == nrow:
+                nc = (m - pos) // nrow
+                dst[pos:pos + nc * nrow].reshape(nc, nrow)[...] = a[:, c0:c0 + nc].T
+                c0 += nc
+                pos += nc * nrow
+            else:
+                dst[pos:pos + take] = a[r0:r0 + take, c0]
+                pos += take
+                r0 += take
+                if r0 == nrow:
+                    r0, c0 = 0, c0 + 1
+    return fill
+
 
 class Context:
     """One GPU, one HIP stream (torch's current stream), one workspace pool."""
@@ -32,9 +70,12 @@ class Context:
         _lib.call("bigkrls_ctx_create_on_stream", self.device_index, C.c_void_p(stream), C.byref(h))
         self.handle = h
         self._events = []
+        self._stage = None
+        self._stage_np = None
 
     def close(self):
         if self.handle is not None:
+            self.release_events()
             _lib.load().bigkrls_ctx_destroy(self.handle)
             self.handle = None
 
@@ -72,12 +113,77 @@ class Context:
         t = self.torch.zeros((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)
         return DeviceMatrix(self, t)
 
+    # ---- transfers ------------------------------------------------------------
+    def _staging(self, n: int):
+        want = min(max(int(n), _STAGE_MIN), _STAGE_MAX)
+        if self._stage is None or self._stage.numel() < want:
+            self._stage = self._stage_np = None
+            self._stage = self.torch.empty(want, dtype=self.torch.float64, pin_memory=True)
+            self._stage_np = self._stage.numpy()
+        return self._stage, self._stage_np
+
+    def _pieces(self, n: int):
+        """(offset, length, staging offset) of the pieces an n-element transfer is cut into."""
+        stage, _ = self._staging(n)
+        if n <= stage.numel():
+            return [(0, n, 0)]
+        half = stage.numel() // 2
+        return [(off, min(half, n - off), (i % 2) * half) for i, off in enumerate(range(0, n, half))]
+
+    def upload_into(self, flat_dev, fill):
+        """Fill the 1-D device tensor `flat_dev`; `fill(dst, off, m)` writes elements [off, off+m)
+        of the source into the host array `dst` (a slice of the pinned staging buffer)."""
+        n = int(flat_dev.numel())
+        if n == 0:
+            return
+        pieces = self._pieces(n)
+        stage, snp = self._stage, self._stage_np
+        done = [None, None]
+        for i, (off, m, so) in enumerate(pieces):
+            if done[i % 2] is not None:
+                done[i % 2].synchronize()       # this half's previous copy has left the host
+            fill(snp[so:so + m], off, m)
+            flat_dev[off:off + m].copy_(stage[so:so + m], non_blocking=True)
+            done[i % 2] = self.torch.cuda.Event()
+            done[i % 2].record()
+        for e in done:
+            if e is not None:
+                e.synchronize()
+
+    def download(self, t) -> np.ndarray:
+        """Host copy (C order, same shape) of a contiguous device tensor."""
+        flat = t.reshape(-1)
+        n = int(flat.numel())
+        out = np.empty(n, dtype=np.float64)
+        if n == 0:
+            return out.reshape(tuple(t.shape))
+        pieces = self._pieces(n)
+        stage, snp = self._stage, self._stage_np
+        events = []
+        for i, (off, m, so) in enumerate(pieces):
+            if i >= 2:                          # the half is free once its previous piece is on the host
+                poff, pm, pso = pieces[i - 2]
+                events[i - 2].synchronize()
+                out[poff:poff + pm] = snp[pso:pso + pm]
+            stage[so:so + m].copy_(flat[off:off + m], non_blocking=True)
+            e = self.torch.cuda.Event()
+            e.record()
+            events.append(e)
+        for i in range(max(0, len(pieces) - 2), len(pieces)):
+            poff, pm, pso = pieces[i]
+            events[i].synchronize()
+            out[poff:poff + pm] = snp[pso:pso + pm]
+        return out.reshape(tuple(t.shape))
+
     def from_numpy(self, a: np.ndarray) -> "DeviceMatrix":
         a = np.asarray(a, dtype=np.float64)
         if a.ndim == 1:
             a = a[:, None]
+        nrow, ncol = a.shape
         # (ncol, nrow) C-contiguous == (nrow, ncol) column-major
-        t = self.torch.from_numpy(np.ascontiguousarray(a.T)).to(self.device)
+        t = self.torch.empty((ncol, nrow), dtype=self.torch.float64, device=self.device)
+        fill = _column_major_filler(a)
+        self.upload_into(t.view(-1), fill)
         return DeviceMatrix(self, t)
 
     # ---- HIP-event timing on the context's stream ----------------------------
@@ -87,6 +193,13 @@ class Context:
         self._events.append(e)
         _lib.call("bigkrls_event_record", self.handle, e)
         return e
+
+    def release_events(self, events=None):
+        """Destroy HIP events made by `event()` (all of them when `events` is None)."""
+        for e in list(self._events if events is None else events):
+            _lib.call("bigkrls_event_destroy", e)
+            if e in self._events:
+                self._events.remove(e)
 
     @staticmethod
     def elapsed_ms(e0, e1) -> float:
@@ -131,7 +244,8 @@ class DeviceMatrix:
         return DeviceMatrix(self.ctx, self.t[c0:c1])
 
     def to_numpy(self) -> np.ndarray:
-        return self.t.cpu().numpy().T.copy()
+        # (ncol, nrow) C order is (nrow, ncol) column-major: return the Fortran-ordered view
+        return self.ctx.download(self.t.contiguous()).T
 
     def __getitem__(self, idx):  # R's `K[]` idiom: materialise on the host
         return self.to_numpy()[idx]

@@ -38,6 +38,14 @@ from .api import BigKRLS, _cor, _sd, _var
 from .device import Context, DeviceMatrix
 
 
+def _host(backend, t):
+    """numpy copy (same shape, C order) of a backend tensor; HBM tensors come down through the
+    context's pinned staging buffer (device.py), CPU tensors (the gloo tests) are viewed."""
+    if t.is_cuda:
+        return backend.ctx.download(t.contiguous())
+    return t.contiguous().numpy()
+
+
 def partition(n: int, world: int):
     """Equal blocks of nb = ceil(n/world) rows; the last ranks may be short or empty."""
     nb = (n + world - 1) // world
@@ -234,7 +242,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         """Orthonormalise the columns of W (tensor (b, n)); returns (Q, R host upper, ok)."""
         Racc = None
         for _ in range(2):
-            G = backend.mm(True, False, W, W).cpu().numpy().T       # b x b
+            G = _host(backend, backend.mm(True, False, W, W)).T         # b x b
             G = 0.5 * (G + G.T)
             R, Rinv = _chol_upper_and_inverse(G)                     # G = R'R (no threaded LAPACK: b is 128)
             if R is None:
@@ -272,7 +280,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         for pas in range(2):                                          # classical Gram-Schmidt, twice
             Cc = backend.mm(True, False, Bv, W)                       # dim x b
             if pas == 0:
-                Aj = Cc[:, steps * b:(steps + 1) * b].cpu().numpy().T.copy()
+                Aj = _host(backend, Cc[:, steps * b:(steps + 1) * b]).T.copy()
             W = backend.mm(False, False, Bv, Cc, alpha=-1.0, beta=1.0, out=W)
         _tick("cgs2", _t0); _t0 = _t.perf_counter()
         W, R, ok = cholqr2(W)
@@ -293,7 +301,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             theta, Y = backend.dense_eig_top(T, neig)                 # Y: (neig, m)
             worst = 0.0
             if ok:
-                Ylast = Y[:, m - b:].cpu().numpy().T                  # b x neig
+                Ylast = _host(backend, Y[:, m - b:]).T                     # b x neig
                 worst = float(np.max(np.linalg.norm(Bblk[-1] @ Ylast, axis=0)))
             if worst <= tol * abs(theta[0]) or last:
                 converged = worst <= tol * abs(theta[0])
@@ -313,7 +321,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     dim = steps * b
     Q = backend.mm(False, False, Ball[:dim], Y)                       # n x neig
     KQ = k_times(Q)
-    H = backend.mm(True, False, Q, KQ).cpu().numpy().T
+    H = _host(backend, backend.mm(True, False, Q, KQ)).T
     H = 0.5 * (H + H.T)
     hv, Zr = backend.dense_eig_top(H, neig)
     vals = np.asarray(hv[:neig], dtype=np.float64)
@@ -430,8 +438,8 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
         Le, c_full = le_loc, c_loc
     yhat_loc = backend.gemv_t(Kcols, c_full)
     yhat_full = _all_gather_vec(torch, dist, yhat_loc, nb, n, world) if world > 1 else yhat_loc
-    coeffs = c_full.cpu().numpy().ravel()
-    yfitted = yhat_full.cpu().numpy().ravel()
+    coeffs = _host(backend, c_full).ravel()
+    yfitted = _host(backend, yhat_full).ravel()
     mark("coeffs")
     resid = ys - yfitted
     sigmasq = float(resid @ resid) / n
@@ -453,7 +461,7 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
         else:
             D_full, S_full = D_loc, S_loc
         var = backend.deriv_var(Q, wv, S_full, ops.deriv_scales(Xe_h, isb, sigma))
-        derivmat = D_full.cpu().numpy().T.copy()
+        derivmat = _host(backend, D_full).T.copy()
         mark("derivatives")
         w["derivatives.std"] = derivmat.copy()
         w["var.avgderivatives.std"] = var.copy()

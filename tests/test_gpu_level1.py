@@ -341,3 +341,26 @@ def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, ne
     ref = orc.b_eigen(K.to_numpy(), neig, trunc)                   # ARPACK
     assert ref.lastkeeper == a.lastkeeper
     assert np.max(np.abs(a.values - ref.values)) <= 1e-9 * ref.values[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,order", [((1000, 7), "C"), ((1000, 7), "F"), ((1, 1), "C"), ((5, 0), "C"),
+                                         ((3000, 3001), "C")])
+def test_host_device_transfers_round_trip(ctx, monkeypatch, shape, order):
+    """from_numpy / to_numpy go through the context's pinned staging buffer; with a small
+    buffer the transfer is cut into pieces that straddle columns (the pipelined path that
+    N x N matrices above 128 MB take)."""
+    from bigkrls_amd import device
+    if shape[0] * shape[1] > 1 << 20:
+        monkeypatch.setattr(device, "_STAGE_MAX", 1 << 20)
+        monkeypatch.setattr(ctx, "_stage", None)
+    rng = np.random.default_rng(5)
+    a = np.asarray(rng.standard_normal(shape), order=order)
+    d = ctx.from_numpy(a)
+    assert d.shape == shape
+    back = d.to_numpy()
+    assert back.shape == shape and np.array_equal(back, a)
+    if a.size:
+        sl = ctx.from_numpy(a[::2, 1:])              # neither C- nor F-contiguous
+        assert np.array_equal(sl.to_numpy(), a[::2, 1:])
+        assert np.array_equal(d.cols(1, 3).to_numpy(), a[:, 1:3])
