@@ -77,7 +77,8 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     if X is None or y is None:
         raise ValueError("y and X are required")
     return_big_rectangles = is_device_matrix(X)                                  # :149
-    Xh = np.array(_as_host_matrix(X), dtype=np.float64)
+    # column-major like R: the per-column statistics below and the upload read contiguous columns
+    Xh = np.array(_as_host_matrix(X), dtype=np.float64, order="F")
     yh = np.array(_as_host_matrix(y), dtype=np.float64).ravel()
     n, p = Xh.shape
     return_big_squares = return_big_rectangles or n > 2500                       # :150
@@ -126,7 +127,7 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     y_init = yh.copy()
     y_init_sd = _sd(y_init)                                                       # :248
     y_init_mean = float(y_init.mean())
-    Xs = (Xh - Xh.mean(axis=0)) / Xh.std(axis=0, ddof=1)                          # :251-253
+    Xs = (Xh - Xh.mean(axis=0)) / X_init_sd                                       # :251-253
     ys = (yh - yh.mean()) / _sd(yh)                                               # :254
 
     T = timings if timings is not None else {}

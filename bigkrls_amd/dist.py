@@ -349,10 +349,11 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     rank = dist.get_rank() if dist.is_initialized() else 0
     if backend is None:
         backend = HipBackend(ctx or Context())
-    Xh = np.array(X, dtype=np.float64)
+    Xh = np.array(X, dtype=np.float64, order="F")
     yh = np.array(y, dtype=np.float64).ravel()
     n, p = Xh.shape
-    if Xh.std(axis=0, ddof=1).min() == 0:
+    X_init_sd = Xh.std(axis=0, ddof=1)
+    if X_init_sd.min() == 0:
         raise ValueError("The following columns in X are constant and must be removed")
     if n != yh.shape[0]:
         raise ValueError("nrow(X) not equal to number of elements in y.")
@@ -360,7 +361,6 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     if eigtrunc is None:
         eigtrunc = 0.001 if n > 3000 else 0.0
     sigma = float(p) if sigma is None else float(sigma)
-    X_init_sd = Xh.std(axis=0, ddof=1)
     y_init_sd, y_init_mean = _sd(yh), float(yh.mean())
     Xs = (Xh - Xh.mean(axis=0)) / X_init_sd
     ys = (yh - y_init_mean) / y_init_sd

@@ -271,7 +271,13 @@ def matvec(A: DeviceMatrix, x: DeviceMatrix, trans: bool = False) -> DeviceMatri
 # ---------------------------------------------------------------------------
 def binary_columns(Xhost: np.ndarray) -> np.ndarray:
     """src/bigderiv_v3.cpp:28-31: a column with exactly two distinct values."""
-    return np.array([np.unique(Xhost[:, j]).size == 2 for j in range(Xhost.shape[1])])
+    out = np.zeros(Xhost.shape[1], dtype=bool)
+    for j in range(Xhost.shape[1]):
+        col = Xhost[:, j]
+        if col.size:
+            lo, hi = col.min(), col.max()          # exactly two distinct values <=> everything is lo or hi
+            out[j] = bool(lo != hi and np.all((col == lo) | (col == hi)))
+    return out
 
 
 def deriv_scales(Xhost: np.ndarray, is_binary: np.ndarray, sigma: float) -> np.ndarray:
