@@ -28,6 +28,8 @@
 #include <numeric>
 #include <cstdlib>
 #include <string>
+#include <chrono>
+#include <cstdio>
 
 namespace bk {
 namespace {
@@ -695,6 +697,97 @@ __global__ void dc_copy_deflated(const MergeDesc* __restrict__ descs,
   for (int r = threadIdx.x; r < d.m; r += blockDim.x) b[r] = a[r];
 }
 
+// ---- top levels kept factored (few eigenvectors wanted) --------------------------------------
+// yf[s+t] = first row of the left child's eigenvector matrix (t < n1, else 0), yl[s+t] = last row
+// of the right child's (t >= n1, else 0): the first and last row of the parent's block matrix
+__global__ void dc_gather_rows(const MergeDesc* __restrict__ descs, const double* __restrict__ Q,
+                               int64_t ld, double* __restrict__ yf, double* __restrict__ yl) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.m) return;
+  const int64_t col = (int64_t)(d.s + t) * ld;
+  yf[d.s + t] = (t < d.n1) ? Q[d.s + col] : 0.0;
+  yl[d.s + t] = (t < d.n1) ? 0.0 : Q[d.s + d.m - 1 + col];
+}
+
+// of[s+j] = sum_i gf[s+i] U[i,j], ol likewise: first / last row of the merged eigenvector matrix
+// (non-deflated columns) from the gathered, rotated rows of the children -- one block per column
+__global__ __launch_bounds__(256) void dc_rows_times_u(const MergeDesc* __restrict__ descs,
+                                                       const double* __restrict__ gf,
+                                                       const double* __restrict__ gl,
+                                                       const double* __restrict__ U, int64_t ld,
+                                                       double* __restrict__ of, double* __restrict__ ol) {
+  __shared__ double sh[4];
+  const MergeDesc d = descs[blockIdx.y];
+  const int j = blockIdx.x;
+  if (j >= d.K) return;
+  const double* u = U + d.s + (int64_t)(d.s + j) * ld;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < d.K; i += 256) {
+    const double v = u[i];
+    a += gf[d.s + i] * v;
+    b += gl[d.s + i] * v;
+  }
+  a = bsum256(a, sh);
+  b = bsum256(b, sh);
+  if (threadIdx.x == 0) { of[d.s + j] = a; ol[d.s + j] = b; }
+}
+
+// X[:, t] = column src_cols[t] of the root's merge operator (X zeroed beforehand): a non-deflated
+// column c < K carries U[:, c] in the rows srccol, a deflated one is a unit vector
+__global__ void dc_lazy_root_x(int nv, const int* __restrict__ cols, int K,
+                               const int* __restrict__ srccol, const int* __restrict__ defsrc,
+                               const double* __restrict__ U, int64_t ldu, double* __restrict__ X,
+                               int64_t ldx) {
+  const int t = blockIdx.x;
+  if (t >= nv) return;
+  const int c = cols[t];
+  double* x = X + (int64_t)t * ldx;
+  if (c < K) {
+    const double* u = U + (int64_t)c * ldu;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) x[srccol[i]] = u[i];
+  } else if (threadIdx.x == 0) {
+    x[defsrc[c - K]] = 1.0;
+  }
+}
+
+// Xn = (merge operator) X for every merge of a level: rows srccol take T = U X[0:K], rows defsrc
+// take the deflated rows X[K:m]
+__global__ void dc_lazy_scatter(const MergeDesc* __restrict__ descs, const int* __restrict__ srccol,
+                                const int* __restrict__ defsrc, const double* __restrict__ Tm,
+                                const double* __restrict__ X, double* __restrict__ Xn, int64_t ld) {
+  const MergeDesc d = descs[blockIdx.y];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= d.m) return;
+  const int64_t col = (int64_t)blockIdx.z * ld;
+  if (r < d.K) Xn[d.s + srccol[d.s + r] + col] = Tm[d.s + r + col];
+  else Xn[d.s + defsrc[d.s + r - d.K] + col] = X[d.s + r + col];
+}
+
+// the recorded column rotations Q <- Q G_1 ... G_r of a merge, moved to the other factor:
+// X <- G_1 (G_2 (... (G_r X))) on the rows of X, one thread per column of X
+__global__ void dc_lazy_rotate(const MergeDesc* __restrict__ descs, const int* __restrict__ merge_ids,
+                               const int* __restrict__ ra, const int* __restrict__ rb,
+                               const double* __restrict__ rc, const double* __restrict__ rs,
+                               double* __restrict__ X, int64_t ld, int nv) {
+  const MergeDesc d = descs[merge_ids[blockIdx.y]];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv) return;
+  double* x = X + d.s + (int64_t)t * ld;
+  for (int i = d.nrot - 1; i >= 0; --i) {
+    const int a = ra[d.rot_off + i], b = rb[d.rot_off + i];
+    const double c = rc[d.rot_off + i], s = rs[d.rot_off + i];
+    const double xa = x[a], xb = x[b];
+    x[a] = c * xa - s * xb;
+    x[b] = s * xa + c * xb;
+  }
+}
+
+__global__ void dc_iota(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
 __global__ void gather_cols(int n, int nv, const int* __restrict__ src, const double* __restrict__ Q,
                             int64_t ldq, double* __restrict__ Z, int64_t ldz) {
   const int64_t total = (int64_t)n * nv;
@@ -715,6 +808,15 @@ struct Node {
 struct LevelArrays {
   std::vector<double> dlam, w, rc, rs;
   std::vector<int> rowpos, pole_of_row, srccol, cpos, defsrc, defdst, ra, rb;
+};
+
+// one level whose merge operators stay factored (see divide_conquer)
+struct LazyLevel {
+  std::vector<MergeDesc> descs;
+  std::vector<int> srccol, defsrc, ra, rb, rot_merges;
+  std::vector<double> rc, rs;
+  std::vector<int64_t> stash_off;   // offset of every merge's K x K secular-vector block in the stash
+  int max_m = 0, maxK = 0;
 };
 
 void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, MergeDesc& md,
@@ -800,7 +902,8 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
 int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                    const std::vector<double>& he, double* Q0, double* Q1, double* U,
                    int64_t n_vals, int64_t n_vecs_max, double keep_thresh,
-                   std::vector<double>& vals_desc, std::vector<int>& src_cols, double** Qfinal) {
+                   std::vector<double>& vals_desc, std::vector<int>& src_cols, double** Qfinal,
+                   bool allow_lazy = true) {
   hipStream_t st = ctx->stream;
   const int64_t N = n;
   // ---- tree -----------------------------------------------------------------
@@ -849,7 +952,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   BK_CHECK_LAUNCH();
   // double arrays: z, dlam, w, lam, zhat, rc, rs  (7n) ; int arrays: 8n ; descs
   void* pd = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_EIG_MISC, (int64_t)8 * n * sizeof(double), &pd));
+  BK_TRY(ws_get(ctx, SLOT_EIG_MISC, (int64_t)12 * n * sizeof(double), &pd));
   double* d_z = (double*)pd;
   double* d_dlam = d_z + n;
   double* d_w = d_dlam + n;
@@ -857,8 +960,12 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   double* d_zhat = d_lam + n;
   double* d_rc = d_zhat + n;
   double* d_rs = d_rc + n;
+  double* d_gf = d_rs + n;      // factored levels: gathered first / last rows in, merged rows out
+  double* d_gl = d_gf + n;
+  double* d_of = d_gl + n;
+  double* d_ol = d_of + n;
   void* pi = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)10 * n * sizeof(int), &pi));
+  BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)11 * n * sizeof(int), &pi));
   int* d_rowpos = (int*)pi;
   int* d_pole = d_rowpos + n;
   int* d_srccol = d_pole + n;
@@ -868,6 +975,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   int* d_ra = d_defdst + n;
   int* d_rb = d_ra + n;
   int* d_rotids = d_rb + n;
+  int* d_iota = d_rotids + n;
   const int max_merges = n / 2 + 1;
   void* pdesc = nullptr;
   BK_TRY(ws_get(ctx, SLOT_EIG_DESC,
@@ -884,10 +992,32 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   A.defsrc.resize(n); A.defdst.resize(n);
 
   int64_t nv_final = 0;
+  const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
+  // Few eigenvectors wanted (truncation or Neig << N): the merge operators of the top LAZY_TOP
+  // levels below the root stay factored. Q of depth Dl+1 is the last one formed; above it only the
+  // first and last row of every node's eigenvector matrix (what the parent's z needs) are
+  // propagated, the K x K secular-vector blocks are stashed, and at the end the operators are
+  // applied right-to-left to the N x nv kept columns of the root:
+  //   Q[:, kept] = Q_{Dl+1} M_Dl ... M_1 M_0[:, kept]      (2 K^2 nv flops per merge instead of 2 m K^2).
+  // BIGKRLS_DC=explicit forms every level, =factored forces this path at any size; a root that
+  // keeps more than N/8 columns redoes the divide & conquer explicitly.
+  constexpr int LAZY_TOP = 3;
+  const char* dc_env = getenv("BIGKRLS_DC");
+  const std::string dc_mode = dc_env ? dc_env : "";
+  const bool lazy = allow_lazy && maxdepth - 1 > LAZY_TOP && dc_mode != "explicit" &&
+                    ((n >= 4096 && (keep_thresh > 0.0 || n_vecs_max * 8 <= N)) ||
+                     (dc_mode == "factored" && n >= 128));   // (forced: the tests run small hard spectra)
+  const int Dl = lazy ? LAZY_TOP : -1;
+  std::vector<LazyLevel> lazy_levels(lazy ? Dl + 1 : 0);   // indexed by depth
+  std::vector<double> bf, bl, yf, yl;                      // boundary rows of the current frontier / of a level
+  double* stash = nullptr;
+  int64_t stash_used = 0;
+  if (lazy) { bf.assign(n, 0.0); bl.assign(n, 0.0); yf.assign(n, 0.0); yl.assign(n, 0.0); }
   for (int depth = maxdepth - 1; depth >= 0; --depth) {
     const std::vector<int>& ids = by_depth[depth];
     const int nm = (int)ids.size();
     if (nm == 0) continue;
+    const auto t_level = std::chrono::steady_clock::now();
     std::vector<MergeDesc> descs(nm);
     int max_m = 0;
     for (int q = 0; q < nm; ++q) {
@@ -896,15 +1026,37 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       descs[q].s = P.s; descs[q].n1 = nodes[P.left].m; descs[q].m = P.m;
       max_m = std::max(max_m, P.m);
     }
+    const bool lazy_level = lazy && depth <= Dl;   // this level's merge operators stay factored
+    const bool lazy_kids = lazy && depth < Dl;     // ... and so do the children's eigenvector matrices
     BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
-    for (int b0 = 0; b0 < nm; b0 += 65535) {
-      const int nb = std::min(65535, nm - b0);
-      hipLaunchKernelGGL(dc_gather_z, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
-                         (const MergeDesc*)(d_descs + b0), (const double*)Qc, N, d_z);
+    if (!lazy_kids) {
+      for (int b0 = 0; b0 < nm; b0 += 65535) {
+        const int nb = std::min(65535, nm - b0);
+        hipLaunchKernelGGL(dc_gather_z, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
+                           (const MergeDesc*)(d_descs + b0), (const double*)Qc, N, d_z);
+        if (lazy_level)
+          hipLaunchKernelGGL(dc_gather_rows, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
+                             (const MergeDesc*)(d_descs + b0), (const double*)Qc, N, d_gf, d_gl);
+      }
+      BK_CHECK_LAUNCH();
+      BK_HIP(hipMemcpyAsync(hz.data(), d_z, n * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (lazy_level) {
+        BK_HIP(hipMemcpyAsync(yf.data(), d_gf, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipMemcpyAsync(yl.data(), d_gl, n * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
+      BK_HIP(hipStreamSynchronize(st));
+    } else {
+      for (int q = 0; q < nm; ++q) {
+        const MergeDesc& md = descs[q];
+        for (int t = 0; t < md.m; ++t) {
+          const bool left = t < md.n1;
+          hz[md.s + t] = left ? bl[md.s + t] : bf[md.s + t];
+          yf[md.s + t] = left ? bf[md.s + t] : 0.0;
+          yl[md.s + t] = left ? 0.0 : bl[md.s + t];
+        }
+      }
+      BK_HIP(hipStreamSynchronize(st));
     }
-    BK_CHECK_LAUNCH();
-    BK_HIP(hipMemcpyAsync(hz.data(), d_z, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    BK_HIP(hipStreamSynchronize(st));
 
     // host deflation scans
     A.ra.clear(); A.rb.clear(); A.rc.clear(); A.rs.clear();
@@ -928,6 +1080,21 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       const int K = descs[0].K, s = descs[0].s;
       for (int j = 0; j < K; ++j) A.cpos[s + j] = K - 1 - j;
     }
+    if (lazy_level && !is_root) {
+      // the deflation rotations act on the columns of the children's matrices, hence on yf, yl
+      for (int q = 0; q < nm; ++q) {
+        const MergeDesc& md = descs[q];
+        double* f = yf.data() + md.s;
+        double* l = yl.data() + md.s;
+        for (int t = 0; t < md.nrot; ++t) {
+          const int a = A.ra[md.rot_off + t], b = A.rb[md.rot_off + t];
+          const double c = A.rc[md.rot_off + t], sn = A.rs[md.rot_off + t];
+          const double fa = f[a], fb = f[b], la = l[a], lb = l[b];
+          f[a] = c * fa + sn * fb; f[b] = c * fb - sn * fa;
+          l[a] = c * la + sn * lb; l[b] = c * lb - sn * la;
+        }
+      }
+    }
     BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_dlam, A.dlam.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_w, A.w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -946,7 +1113,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       BK_HIP(hipMemcpyAsync(d_rotids, rot_merges.data(), rot_merges.size() * sizeof(int),
                             hipMemcpyHostToDevice, st));
       const int nrm = (int)rot_merges.size();
-      for (int b0 = 0; b0 < nrm; b0 += 65535) {
+      for (int b0 = 0; b0 < nrm && !lazy_kids; b0 += 65535) {
         const int nb = std::min(65535, nrm - b0);
         hipLaunchKernelGGL(dc_rotate, dim3((max_m + 63) / 64, nb), dim3(64), 0, st,
                            (const MergeDesc*)d_descs, (const int*)(d_rotids + b0), (const int*)d_ra,
@@ -1009,6 +1176,12 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         if (ord[t] < descs[0].K) ++kneed;
       }
       descs[0].Kneed = kneed;
+      if (lazy && nv * 8 > N) {
+        BK_HIP(hipStreamSynchronize(st));
+        if (verbose) fprintf(stderr, "[bigkrls]   d&c: %lld columns kept, redoing the top levels explicitly\n", (long long)nv);
+        return divide_conquer(ctx, n, hd, he, Q0, Q1, U, n_vals, n_vecs_max, keep_thresh, vals_desc,
+                              src_cols, Qfinal, false);
+      }
       BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
     }
     // eigenvector update
@@ -1021,6 +1194,61 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, U, N);
       }
       BK_CHECK_LAUNCH();
+    }
+    if (lazy_level) {
+      LazyLevel& L = lazy_levels[depth];
+      L.descs = descs;
+      L.srccol = A.srccol; L.defsrc = A.defsrc;
+      L.max_m = max_m; L.maxK = maxK;
+      if (lazy_kids) {   // (at depth Dl the rotations went into the explicit Q of depth Dl+1)
+        L.ra = A.ra; L.rb = A.rb; L.rc = A.rc; L.rs = A.rs; L.rot_merges = rot_merges;
+      } else {
+        for (auto& md : L.descs) md.nrot = 0;
+      }
+      if (!is_root) {
+        // stash the secular-vector blocks (the U buffer is reused by the next level) in the idle
+        // ping-pong copy of Q, and push the boundary rows through the merge
+        if (stash == nullptr) stash = Qn;
+        L.stash_off.resize(nm);
+        std::vector<double> gfh(n, 0.0), glh(n, 0.0);
+        for (int q = 0; q < nm; ++q) {
+          const MergeDesc& md = descs[q];
+          L.stash_off[q] = stash_used;
+          if (md.K > 0)
+            BK_HIP(hipMemcpy2DAsync(stash + stash_used, (size_t)md.K * sizeof(double),
+                                    U + md.s + (int64_t)md.s * N, (size_t)N * sizeof(double),
+                                    (size_t)md.K * sizeof(double), (size_t)md.K, hipMemcpyDeviceToDevice, st));
+          stash_used += (int64_t)md.K * md.K;
+          for (int i = 0; i < md.K; ++i) {
+            gfh[md.s + i] = yf[md.s + A.srccol[md.s + i]];
+            glh[md.s + i] = yl[md.s + A.srccol[md.s + i]];
+          }
+        }
+        BK_HIP(hipMemcpyAsync(d_gf, gfh.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        BK_HIP(hipMemcpyAsync(d_gl, glh.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (maxK > 0) {
+          for (int b0 = 0; b0 < nm; b0 += 65535) {
+            const int nb = std::min(65535, nm - b0);
+            hipLaunchKernelGGL(dc_rows_times_u, dim3(maxK, nb), dim3(256), 0, st,
+                               (const MergeDesc*)(d_descs + b0), (const double*)d_gf, (const double*)d_gl,
+                               (const double*)U, N, d_of, d_ol);
+          }
+          BK_CHECK_LAUNCH();
+        }
+        std::vector<double> ofh(n), olh(n);
+        BK_HIP(hipMemcpyAsync(ofh.data(), d_of, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipMemcpyAsync(olh.data(), d_ol, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipStreamSynchronize(st));
+        for (int q = 0; q < nm; ++q) {
+          const MergeDesc& md = descs[q];
+          for (int j = 0; j < md.K; ++j) { bf[md.s + j] = ofh[md.s + j]; bl[md.s + j] = olh[md.s + j]; }
+          for (int t = 0; t < md.m - md.K; ++t) {
+            bf[md.s + md.K + t] = yf[md.s + A.defsrc[md.s + t]];
+            bl[md.s + md.K + t] = yl[md.s + A.defsrc[md.s + t]];
+          }
+        }
+      }
+    } else if (maxKneed > 0) {
       std::vector<GemmDesc> gd;
       gd.reserve(2 * nm);
       int gm = 0, gn = 0;
@@ -1047,7 +1275,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
       BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, gn));
     }
-    if (max_ndef > 0) {
+    if (max_ndef > 0 && !lazy_level) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
         hipLaunchKernelGGL(dc_copy_deflated, dim3(max_ndef, nb), dim3(64), 0, st,
@@ -1058,12 +1286,108 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     }
     // host vectors (gd, descs) must outlive the async copies
     BK_HIP(hipStreamSynchronize(st));
-    std::swap(Qc, Qn);
+    if (!lazy_level) std::swap(Qc, Qn);
+    if (verbose)
+      fprintf(stderr, "[bigkrls]   d&c depth %2d%s: %6d merges, largest %6d (non-deflated %6d, %d rotations) %8.2f ms\n",
+              depth, lazy_level ? " (factored)" : "", nm, max_m, maxK, (int)A.ra.size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
   }
   if (n == 1) {
     vals_desc.assign(1, dadj[0]);
     src_cols.assign(1, 0);
     nv_final = 1;
+  }
+  if (lazy) {
+    // ---- apply the factored levels to the kept columns, root first ---------------------------
+    const auto t_apply = std::chrono::steady_clock::now();
+    const int nv = (int)nv_final;
+    const LazyLevel& R = lazy_levels[0];
+    const int K0 = R.descs[0].K, kc = R.descs[0].Kneed;
+    // the root's secular vectors occupy the first kc columns of U; the rest of U holds X, its
+    // ping-pong partner and the product buffer (nv <= N/8)
+    double* Xa = U + N * (int64_t)kc;
+    double* Xb = Xa + N * (int64_t)nv;
+    double* Tm = Xb + N * (int64_t)nv;
+    BK_HIP(hipMemsetAsync(Xa, 0, (size_t)N * nv * sizeof(double), st));
+    BK_HIP(hipMemcpyAsync(d_cpos, src_cols.data(), nv * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_srccol, R.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_HIP(hipMemcpyAsync(d_defsrc, R.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dc_iota, dim3((n + 255) / 256), dim3(256), 0, st, d_iota, n);
+    hipLaunchKernelGGL(dc_lazy_root_x, dim3(nv), dim3(256), 0, st, nv, (const int*)d_cpos, K0,
+                       (const int*)d_srccol, (const int*)d_defsrc, (const double*)U, N, Xa, N);
+    BK_CHECK_LAUNCH();
+    auto apply_rotations = [&](const LazyLevel& L, double* X) -> int {
+      if (L.ra.empty() || L.rot_merges.empty()) return BIGKRLS_OK;
+      const int nrt = (int)L.ra.size(), nrm = (int)L.rot_merges.size();
+      BK_HIP(hipMemcpyAsync(d_ra, L.ra.data(), nrt * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rb, L.rb.data(), nrt * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rc, L.rc.data(), nrt * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rs, L.rs.data(), nrt * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rotids, L.rot_merges.data(), nrm * sizeof(int), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(dc_lazy_rotate, dim3((nv + 63) / 64, nrm), dim3(64), 0, st,
+                         (const MergeDesc*)d_descs, (const int*)d_rotids, (const int*)d_ra,
+                         (const int*)d_rb, (const double*)d_rc, (const double*)d_rs, X, N, nv);
+      BK_CHECK_LAUNCH();
+      return BIGKRLS_OK;
+    };
+    BK_HIP(hipMemcpyAsync(d_descs, R.descs.data(), sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    BK_TRY(apply_rotations(R, Xa));
+    BK_HIP(hipStreamSynchronize(st));
+    double* cur = Xa;
+    double* oth = Xb;
+    std::vector<GemmDesc> gd;
+    for (int d = 1; d <= Dl; ++d) {
+      const LazyLevel& L = lazy_levels[d];
+      const int nm = (int)L.descs.size();
+      BK_HIP(hipMemcpyAsync(d_descs, L.descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_srccol, L.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_defsrc, L.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+      gd.clear();
+      for (int q = 0; q < nm; ++q) {
+        const MergeDesc& md = L.descs[q];
+        if (md.K <= 0) continue;
+        GemmDesc g{};
+        g.A = stash + L.stash_off[q]; g.B = cur + md.s; g.C = Tm + md.s;
+        g.lda = md.K; g.ldb = N; g.ldc = N;
+        g.m = md.K; g.n = nv; g.k = md.K; g.kidx = d_iota;
+        gd.push_back(g);
+      }
+      if (!gd.empty()) {
+        BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+        BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), L.maxK, nv));
+      }
+      hipLaunchKernelGGL(dc_lazy_scatter, dim3((L.max_m + 255) / 256, nm, nv), dim3(256), 0, st,
+                         (const MergeDesc*)d_descs, (const int*)d_srccol, (const int*)d_defsrc,
+                         (const double*)Tm, (const double*)cur, oth, N);
+      BK_CHECK_LAUNCH();
+      BK_TRY(apply_rotations(L, oth));
+      BK_HIP(hipStreamSynchronize(st));   // the host vectors were sources of asynchronous copies
+      std::swap(cur, oth);
+    }
+    // the explicit eigenvector matrices of depth Dl+1, one block per depth-Dl merge: that level's
+    // deflation rotations were applied to them in place and couple the two children's columns
+    {
+      const LazyLevel& L = lazy_levels[Dl];
+      gd.clear();
+      int gm = 0;
+      for (const MergeDesc& md : L.descs) {
+        GemmDesc g{};
+        g.A = Qc + md.s + (int64_t)md.s * N; g.B = cur + md.s; g.C = oth + md.s;
+        g.lda = N; g.ldb = N; g.ldc = N;
+        g.m = md.m; g.n = nv; g.k = md.m; g.kidx = d_iota;
+        gd.push_back(g);
+        gm = std::max(gm, md.m);
+      }
+      BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+      BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, nv));
+      BK_HIP(hipStreamSynchronize(st));
+    }
+    for (int t = 0; t < nv; ++t) src_cols[t] = t;
+    *Qfinal = oth;
+    if (verbose)
+      fprintf(stderr, "[bigkrls]   d&c: factored levels applied to %d columns %8.2f ms\n", nv,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_apply).count());
+    return BIGKRLS_OK;
   }
   (void)nv_final;
   *Qfinal = Qc;
@@ -1428,6 +1752,17 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   const int n = (int)n64;
   const int64_t N = n;
   hipStream_t st = ctx->stream;
+  // BIGKRLS_VERBOSE: wall-clock of each phase on stderr (adds a stream synchronisation per phase)
+  const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
+  auto t_phase = std::chrono::steady_clock::now();
+  auto tick = [&](const char* name) {
+    if (!verbose) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bigkrls] eigen n=%d: %-28s %8.2f ms\n", n, name,
+            std::chrono::duration<double, std::milli>(now - t_phase).count());
+    t_phase = now;
+  };
   void *pW = nullptr, *pQ0 = nullptr, *pQ1 = nullptr, *pU = nullptr, *pP = nullptr, *pV = nullptr;
   BK_TRY(ws_get(ctx, SLOT_EIG_A, N * N * sizeof(double), &pW));
   BK_TRY(ws_get(ctx, SLOT_EIG_PANEL, 4 * N * TRD_NB * sizeof(double), &pP));
@@ -1487,7 +1822,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
     BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
+    tick("setup + copy");
     BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
+    tick("stage 1 (dense -> band)");
     int blocks = (int)std::min<int64_t>(((int64_t)S2_LD * N + 255) / 256, 8192);
     hipLaunchKernelGGL(s1_extract_band, dim3(blocks), dim3(256), 0, st, (const double*)W, n, AB);
     BK_CHECK_LAUNCH();
@@ -1498,6 +1835,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     int h_err = 0;
     BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
+    tick("stage 2 (band -> tridiagonal)");
     if (h_err != 0) {
       set_error("eigen: watchdog of a persistent kernel fired (its workgroups were not co-resident); "
                 "rerun with BIGKRLS_PQ=steps BIGKRLS_BC=wavefront");
@@ -1524,6 +1862,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   double* Qfin = nullptr;
   BK_TRY(divide_conquer(ctx, n, hd, he, (double*)pQ0, (double*)pQ1, (double*)pU, n_vals,
                         n_vecs_max, keep_thresh, vals_desc, src_cols, &Qfin));
+  tick("divide & conquer");
   BK_HIP(hipMemcpyAsync(vals, vals_desc.data(), n_vals * sizeof(double), hipMemcpyHostToDevice, st));
   const int nv = (int)src_cols.size();
   if (h_n_vecs) *h_n_vecs = nv;
@@ -1546,11 +1885,14 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     double* pvecs = vecs + (int64_t)pc0 * ldv;
     const int pnv = pc1 - pc0;
     if (pnv > 0 && two_stage) {
+      tick("gather kept columns");
       BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv));
+      tick("back-transform stage 2");
       void* pw12 = nullptr;
       BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * pnv * sizeof(double), &pw12));
       BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
                                    (double*)pw12 + (int64_t)S2_B * pnv));
+      tick("back-transform stage 1");
     } else if (pnv > 0) {
       BK_TRY(back_transform(ctx, W, n, tau, pvecs, ldv, pnv));
     }

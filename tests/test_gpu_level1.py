@@ -354,6 +354,7 @@ def test_host_device_transfers_round_trip(ctx, monkeypatch, shape, order):
     if shape[0] * shape[1] > 1 << 20:
         monkeypatch.setattr(device, "_STAGE_MAX", 1 << 20)
         monkeypatch.setattr(ctx, "_stage", None)
+        monkeypatch.setattr(ctx, "_stage_np", None)
     rng = np.random.default_rng(5)
     a = np.asarray(rng.standard_normal(shape), order=order)
     d = ctx.from_numpy(a)
@@ -364,3 +365,49 @@ def test_host_device_transfers_round_trip(ctx, monkeypatch, shape, order):
         sl = ctx.from_numpy(a[::2, 1:])              # neither C- nor F-contiguous
         assert np.array_equal(sl.to_numpy(), a[::2, 1:])
         assert np.array_equal(d.cols(1, 3).to_numpy(), a[:, 1:3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,neig", [("clusters", 1100, 100), ("wilkinson", 1501, 150), ("identity", 640, 64),
+                                         ("rank3", 900, 20), ("graded", 1024, 128), ("kernel", 4300, 200)])
+def test_eigen_divide_conquer_factored_top_levels(ctx, monkeypatch, kind, n, neig):
+    """Few eigenvectors wanted: the top levels of the divide & conquer stay factored (boundary rows
+    propagated, secular-vector blocks stashed, operators applied to the kept columns at the end).
+    Same eigenvalues as with every level formed, orthonormal vectors, rounding-level residuals --
+    including spectra whose merges deflate with rotations (clusters, Wilkinson) or entirely
+    (identity)."""
+    from bigkrls_amd import ops
+    rng = np.random.default_rng(n)
+
+    def with_spectrum(d):
+        Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        return (Qm * d) @ Qm.T
+
+    if kind == "clusters":
+        A = with_spectrum(np.r_[1 + 1e-13 * rng.standard_normal(n // 2), 2 + 1e-13 * rng.standard_normal(n - n // 2)])
+    elif kind == "wilkinson":
+        A = np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    elif kind == "identity":
+        A = np.eye(n)
+    elif kind == "rank3":
+        A = with_spectrum(np.r_[[5.0, 3.0, 1.0], 1e-14 * rng.random(n - 3)])
+    elif kind == "graded":
+        A = with_spectrum(np.logspace(0, -16, n))
+    else:
+        X, _ = orc.synth(n, 6, 41)
+        A = orc.gauss_kernel_literal((X - X.mean(0)) / X.std(0, ddof=1), 6.0)
+    A = (A + A.T) / 2
+    Ad = ctx.from_numpy(A)
+    monkeypatch.setenv("BIGKRLS_EIGK", "dense")
+    monkeypatch.setenv("BIGKRLS_DC", "explicit")
+    e = ops.bEigen(Ad, neig, -1.0)
+    monkeypatch.setenv("BIGKRLS_DC", "factored")
+    f = ops.bEigen(Ad, neig, -1.0)
+    ref = np.linalg.eigvalsh(A)[::-1][:neig]
+    scale = max(np.abs(ref).max(), 1e-300)
+    assert f.lastkeeper == e.lastkeeper == neig
+    assert np.max(np.abs(f.values - e.values)) / scale < 1e-13
+    assert np.max(np.abs(f.values[:neig] - ref)) / scale < 1e-12
+    Q = f.vectors.to_numpy()
+    assert np.max(np.abs(Q.T @ Q - np.eye(neig))) < 1e-11
+    assert np.max(np.abs(A @ Q - Q * f.values[:neig])) / scale < 1e-11
