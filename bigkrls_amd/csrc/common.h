@@ -101,6 +101,7 @@ enum Slot {
   SLOT_KRY_T = 25,
   SLOT_KRY_Y = 26,
   SLOT_SIDE_SPLITK = 27,   // split-K partials of GEMMs issued on the look-ahead stream
+  SLOT_EIG_T2 = 28,        // compact-WY T factors of the stage-2 back-transform tasks
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

@@ -1788,6 +1788,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   const bool two_stage = !(eig_env && std::string(eig_env) == "1stage") && n > 4 * S2_B;
   double *taus1 = nullptr, *AB = nullptr, *VV = nullptr, *TT = nullptr;
   int64_t* d_soff = nullptr;
+  std::vector<int64_t> bt2_toff;      // (source of an asynchronous copy: lives until the function returns)
+  double* bt2_T = nullptr;
+  int64_t* bt2_dtoff = nullptr;
   Stage1Ws s1{};
   if (two_stage) {
     const int64_t nb64 = N * S2_B;
@@ -1836,6 +1839,28 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
     tick("stage 2 (band -> tridiagonal)");
+    // T factors of the stage-2 back-transform tasks (BIGKRLS_BT2=seq: reflector-by-reflector kernel)
+    const char* bt2_env = getenv("BIGKRLS_BT2");
+    if (n_vecs_max > 0 && n >= 3 && !(bt2_env && std::string(bt2_env) == "seq")) {
+      bt2_toff = bt2_task_offsets(n);
+      const int64_t ntasks = bt2_toff.back();
+      void* pt2 = nullptr;
+      BK_TRY(ws_get(ctx, SLOT_EIG_T2,
+                    (ntasks * BT2_G * BT2_G + (int64_t)bt2_toff.size() + 8) * (int64_t)sizeof(double), &pt2));
+      bt2_T = (double*)pt2;
+      bt2_dtoff = (int64_t*)(bt2_T + ntasks * BT2_G * BT2_G);
+      // on the look-ahead stream: they are not needed before the divide & conquer has finished
+      BK_TRY(side_stream_get(ctx));
+      hipStream_t side = ctx->side_stream;
+      BK_HIP(hipEventRecord(ctx->ev_fork, st));
+      BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
+      BK_HIP(hipMemcpyAsync(bt2_dtoff, bt2_toff.data(), bt2_toff.size() * sizeof(int64_t), hipMemcpyHostToDevice, side));
+      const int ngroups = (int)bt2_toff.size() - 1, ntmax = (n - 2) / S2_B + 1;
+      hipLaunchKernelGGL(bt2_build_t, dim3(ntmax, ngroups), dim3(256), 0, side, n, (const int64_t*)d_soff,
+                         (const double*)VV, (const double*)TT, (const int64_t*)bt2_dtoff, bt2_T);
+      BK_CHECK_LAUNCH();
+      BK_HIP(hipEventRecord(ctx->ev_join, side));
+    }
     if (h_err != 0) {
       set_error("eigen: watchdog of a persistent kernel fired (its workgroups were not co-resident); "
                 "rerun with BIGKRLS_PQ=steps BIGKRLS_BC=wavefront");
@@ -1886,7 +1911,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int pnv = pc1 - pc0;
     if (pnv > 0 && two_stage) {
       tick("gather kept columns");
-      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv));
+      if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv, bt2_dtoff, bt2_T));
       tick("back-transform stage 2");
       void* pw12 = nullptr;
       BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * pnv * sizeof(double), &pw12));
@@ -1897,6 +1923,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(back_transform(ctx, W, n, tau, pvecs, ldv, pnv));
     }
   }
+  if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
 }
