@@ -102,6 +102,8 @@ enum Slot {
   SLOT_KRY_Y = 26,
   SLOT_SIDE_SPLITK = 27,   // split-K partials of GEMMs issued on the look-ahead stream
   SLOT_EIG_T2 = 28,        // compact-WY T factors of the stage-2 back-transform tasks
+  SLOT_EIG_VBIG = 29,      // merged reflector blocks of the stage-1 back-transform
+  SLOT_EIG_TBIG = 30,      // ... and their T factors
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

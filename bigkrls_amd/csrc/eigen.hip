@@ -1791,6 +1791,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   std::vector<int64_t> bt2_toff;      // (source of an asynchronous copy: lives until the function returns)
   double* bt2_T = nullptr;
   int64_t* bt2_dtoff = nullptr;
+  Bt1Plan bt1;
+  double *bt1_V = nullptr, *bt1_T = nullptr;
   Stage1Ws s1{};
   if (two_stage) {
     const int64_t nb64 = N * S2_B;
@@ -1834,7 +1836,31 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     // progress flags / error word of the persistent bulge-chasing kernel: the (unused here)
     // tau and scratch vectors of the one-stage path
     int* bc_err = (int*)scratch;
+    // merged block reflectors of the stage-1 back-transform (BIGKRLS_BT1=panel: one panel per step):
+    // built on the look-ahead stream from stage 1's output while the main stream goes on
+    const char* bt1_env = getenv("BIGKRLS_BT1");
+    const bool bt1_grouped = n_vecs_max > 0 && !(bt1_env && std::string(bt1_env) == "panel");
+    constexpr int64_t LT1 = BT1_GRP * S2_B;
+    double* bt1_G = nullptr;
+    if (bt1_grouped) {
+      bt1 = bt1_plan(n);
+      void *pvb = nullptr, *ptb = nullptr;
+      BK_TRY(ws_get(ctx, SLOT_EIG_VBIG, (bt1.vtotal + 16) * (int64_t)sizeof(double), &pvb));
+      BK_TRY(ws_get(ctx, SLOT_EIG_TBIG,
+                    ((int64_t)bt1.k0.size() * LT1 * LT1 + 2 * LT1 * LT1) * (int64_t)sizeof(double), &ptb));
+      bt1_V = (double*)pvb;
+      bt1_T = (double*)ptb;
+      bt1_G = bt1_T + (int64_t)bt1.k0.size() * LT1 * LT1;
+      BK_TRY(side_stream_get(ctx));
+      BK_HIP(hipEventRecord(ctx->ev_fork, st));          // stage 1 (and the band copy) are done
+    }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
+    if (bt1_grouped) {
+      BK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
+                            ctx->side_stream));
+      BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+    }
     int h_err = 0;
     BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
@@ -1852,8 +1878,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // on the look-ahead stream: they are not needed before the divide & conquer has finished
       BK_TRY(side_stream_get(ctx));
       hipStream_t side = ctx->side_stream;
-      BK_HIP(hipEventRecord(ctx->ev_fork, st));
-      BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
+      BK_HIP(hipEventRecord(ctx->ev_join2, st));         // the bulge chasing is done
+      BK_HIP(hipStreamWaitEvent(side, ctx->ev_join2, 0));
       BK_HIP(hipMemcpyAsync(bt2_dtoff, bt2_toff.data(), bt2_toff.size() * sizeof(int64_t), hipMemcpyHostToDevice, side));
       const int ngroups = (int)bt2_toff.size() - 1, ntmax = (n - 2) / S2_B + 1;
       hipLaunchKernelGGL(bt2_build_t, dim3(ntmax, ngroups), dim3(256), 0, side, n, (const int64_t*)d_soff,
@@ -1911,19 +1937,24 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int pnv = pc1 - pc0;
     if (pnv > 0 && two_stage) {
       tick("gather kept columns");
-      if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      if (bt2_T != nullptr || bt1_V != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
       BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv, bt2_dtoff, bt2_T));
       tick("back-transform stage 2");
       void* pw12 = nullptr;
-      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * S2_B * pnv * sizeof(double), &pw12));
-      BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
-                                   (double*)pw12 + (int64_t)S2_B * pnv));
+      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * BT1_GRP * S2_B * pnv * sizeof(double), &pw12));
+      if (bt1_V != nullptr)
+        BK_TRY(back_transform_stage1_grouped(ctx, n, bt1, bt1_V, bt1_T, pvecs, ldv, pnv, (double*)pw12,
+                                             (double*)pw12 + (int64_t)BT1_GRP * S2_B * pnv));
+      else
+        BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
+                                     (double*)pw12 + (int64_t)S2_B * pnv));
       tick("back-transform stage 1");
     } else if (pnv > 0) {
       BK_TRY(back_transform(ctx, W, n, tau, pvecs, ldv, pnv));
     }
   }
-  if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
+  if (bt2_T != nullptr || bt1_V != nullptr)
+    BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
 }

@@ -411,3 +411,32 @@ def test_eigen_divide_conquer_factored_top_levels(ctx, monkeypatch, kind, n, nei
     Q = f.vectors.to_numpy()
     assert np.max(np.abs(Q.T @ Q - np.eye(neig))) < 1e-11
     assert np.max(np.abs(A @ Q - Q * f.values[:neig])) / scale < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [700, 1283])
+def test_eigen_back_transform_variants(lib, monkeypatch, n):
+    """Back-transforms: the compact-WY MFMA kernel of stage 2 and the merged block reflectors of
+    stage 1 (defaults) against the reflector-by-reflector kernel (BIGKRLS_BT2=seq) and the
+    panel-by-panel loop (BIGKRLS_BT1=panel): same eigenvectors up to rounding."""
+    monkeypatch.delenv("BIGKRLS_EIG", raising=False)
+    X, y = orc.synth(n, 4, 23)
+    K = orc.gauss_kernel_literal(X, 4.0)
+    Kf = F(K)
+    out = {}
+    for mode in ("wy", "seq"):
+        if mode == "seq":
+            monkeypatch.setenv("BIGKRLS_BT2", "seq")
+            monkeypatch.setenv("BIGKRLS_BT1", "panel")
+        else:
+            monkeypatch.delenv("BIGKRLS_BT2", raising=False)
+            monkeypatch.delenv("BIGKRLS_BT1", raising=False)
+        vals = np.zeros(n)
+        vecs = F(np.zeros((n, n)))
+        check(lib, lib.bigkrls_eigen(P(Kf), n, n, P(vals), P(vecs)))
+        assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < 1e-11
+        assert np.max(np.abs(K @ vecs - vecs * vals)) / vals[0] < 1e-11
+        out[mode] = (vals, vecs)
+    assert np.array_equal(out["wy"][0], out["seq"][0])
+    # well separated top of the spectrum: the vectors themselves agree
+    assert np.max(np.abs(np.abs(out["wy"][1][:, :5]) - np.abs(out["seq"][1][:, :5]))) < 1e-9
