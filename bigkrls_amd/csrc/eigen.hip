@@ -1852,10 +1852,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       bt1_T = (double*)ptb;
       bt1_G = bt1_T + (int64_t)bt1.k0.size() * LT1 * LT1;
       BK_TRY(side_stream_get(ctx));
-      BK_HIP(hipEventRecord(ctx->ev_fork, st));          // stage 1 (and the band copy) are done
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
     if (bt1_grouped) {
+      // after the bulge chasing (its workgroups fill every CU's LDS; sharing the GPU only slows it
+      // down), i.e. concurrently with the host-bound divide & conquer
+      BK_HIP(hipEventRecord(ctx->ev_fork, st));
       BK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
       BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
                             ctx->side_stream));

@@ -45,6 +45,10 @@ constexpr int LDS_XK = BK + 2;
 #ifndef GEMM_KX_PAD
 #define GEMM_KX_PAD 8
 #endif
+// plain GEMM kernels with tiles up to this width keep two k-tiles in flight (see gemm_tile)
+#ifndef GEMM_DEEP_BN
+#define GEMM_DEEP_BN 64
+#endif
 constexpr int lds_stage(int w) {   // room for either layout
   return BK * (w + GEMM_KX_PAD) > w * LDS_XK ? BK * (w + GEMM_KX_PAD) : w * LDS_XK;
 }
@@ -147,7 +151,7 @@ struct GemmOperands {
 
 // Computes the accumulators of the (m0, n0) block tile over k in [kbeg, kend).
 // TA/TB: operand is used transposed (op(A) = A' with A stored K x M, etc.).
-template <bool TA, bool TB, int BN, bool GATHER = false>
+template <bool TA, bool TB, int BN, bool GATHER = false, bool DEEP = false>
 __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0, int kbeg,
                                           int kend, double* __restrict__ smem,
                                           d4 (&acc)[4][BN / 32]) {
@@ -216,19 +220,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
     pb += ib;
   };
 
-  load_tiles(kbeg);
-  if (kbeg + BK > kend) {
-    tile_zero_ktail<A_CONTIG, BM>(kbeg, kend, ra);
-    tile_zero_ktail<B_CONTIG, BN>(kbeg, kend, rb);
-  }
-  tile_store<A_CONTIG, BM>(smem, ra);
-  tile_store<B_CONTIG, BN>(smem + B_BASE, rb);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const int k0 = kbeg + (t + 1) * BK;
-    if (t + 1 < ntiles) load_tiles(k0);
+  auto mfma_tile = [&](int cur) {
     const double* as = smem + cur * A_STAGE;
     const double* bs = smem + B_BASE + cur * B_STAGE;
 #pragma unroll
@@ -244,6 +236,66 @@ __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int m0, int n0,
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
+  };
+
+  if (DEEP) {
+    // Two k-tiles in flight: the loads of tile t+2 are issued before the MFMAs of tile t, tile t+1
+    // waits in the other register set and goes to LDS after them. A thin tile (BN = 64) has only
+    // ~1.7 us of MFMA work per k-tile and CU -- less than the HBM latency a single tile in flight
+    // would have to hide.
+    double ra2[BM / 16];
+    double rb2[BN / 16];
+    auto load_into = [&](int k0, double (&xa)[BM / 16], double (&xb)[BN / 16]) {
+      const bool full = k0 + BK <= kend;
+      if (full && a_fast) tile_load_strided<BM>(pa, sa, xa);
+      else tile_load<A_CONTIG, BM, GATHER>(g.A, g.lda, m0, k0, g.M, kend, xa, g.kidx);
+      if (full && b_fast) tile_load_strided<BN>(pb, sb, xb);
+      else tile_load<B_CONTIG, BN>(g.B, g.ldb, n0, k0, g.N, kend, xb);
+      pa += ia;
+      pb += ib;
+    };
+    auto stage = [&](int k0, int st, double (&xa)[BM / 16], double (&xb)[BN / 16]) {
+      if (k0 + BK > kend) {
+        tile_zero_ktail<A_CONTIG, BM>(k0, kend, xa);
+        tile_zero_ktail<B_CONTIG, BN>(k0, kend, xb);
+      }
+      tile_store<A_CONTIG, BM>(smem + st * A_STAGE, xa);
+      tile_store<B_CONTIG, BN>(smem + B_BASE + st * B_STAGE, xb);
+    };
+    load_into(kbeg, ra, rb);
+    stage(kbeg, 0, ra, rb);
+    if (ntiles > 1) load_into(kbeg + BK, ra2, rb2);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+      // even tile t: LDS stage 0; tile t+1 waits in (ra2, rb2); tile t+2 loads into (ra, rb)
+      if (t + 2 < ntiles) load_into(kbeg + (t + 2) * BK, ra, rb);
+      mfma_tile(0);
+      if (t + 1 < ntiles) stage(kbeg + (t + 1) * BK, 1, ra2, rb2);
+      __syncthreads();
+      if (t + 1 >= ntiles) break;
+      // odd tile t+1: LDS stage 1; tile t+2 waits in (ra, rb); tile t+3 loads into (ra2, rb2)
+      if (t + 3 < ntiles) load_into(kbeg + (t + 3) * BK, ra2, rb2);
+      mfma_tile(1);
+      if (t + 2 < ntiles) stage(kbeg + (t + 2) * BK, 0, ra, rb);
+      __syncthreads();
+    }
+    return;
+  }
+
+  load_tiles(kbeg);
+  if (kbeg + BK > kend) {
+    tile_zero_ktail<A_CONTIG, BM>(kbeg, kend, ra);
+    tile_zero_ktail<B_CONTIG, BN>(kbeg, kend, rb);
+  }
+  tile_store<A_CONTIG, BM>(smem, ra);
+  tile_store<B_CONTIG, BN>(smem + B_BASE, rb);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const int k0 = kbeg + (t + 1) * BK;
+    if (t + 1 < ntiles) load_tiles(k0);
+    mfma_tile(cur);
     if (t + 1 < ntiles) {
       if (k0 + BK > kend) {  // partial last tile: k rows past the end must contribute zeros
         tile_zero_ktail<A_CONTIG, BM>(k0, kend, ra);
@@ -309,7 +361,7 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, doub
   const int kbeg = z * k_chunk;
   const int kend = min(g.K, kbeg + k_chunk);
   d4 acc[4][BN / 32];
-  gemm_tile<TA, TB, BN>(g, m0, n0, kbeg, kend, smem, acc);
+  gemm_tile<TA, TB, BN, false, (BN <= GEMM_DEEP_BN)>(g, m0, n0, kbeg, kend, smem, acc);
   if (partial != nullptr) {
     double* P = partial + (int64_t)z * g.M * g.N;
     const int M = g.M, N = g.N;
