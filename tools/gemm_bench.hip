@@ -2,6 +2,8 @@
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_bench.hip -o tools/gemm_bench -Lbigkrls_amd -lbigkrls_hip -Wl,-rpath,'$ORIGIN/../bigkrls_amd'
 #include "../bigkrls_amd/csrc/common.h"
 #include <cstdio>
+#include <vector>
+#include <algorithm>
 #include <cstdlib>
 #include <chrono>
 using namespace bk;
@@ -53,6 +55,24 @@ int main(int argc, char** argv) {
     wall("syrk_mirror<64> || A22 V (two streams)", [&] {
       syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, -1, true);
       gemm(ctx2, 0, 0, n, 64, n, 1.0, C2, n, A, n, 0.0, Y, n); });
+    // mixed tile shapes on two streams: do workgroups with different MFMA / epilogue phase lengths
+    // overlap better than identical ones running in lockstep?
+    const int tiles = (int)((n + 127) / 128);
+    for (int cut : {tiles / 8, tiles / 5, tiles / 4, tiles / 3}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "syrk<128> cols [0,%d) || syrk<64> cols [%d,%d)", cut, cut, tiles);
+      wall(nm, [&] {
+        syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, cut, false);
+        syrk_mirror(ctx2, n, 128, -1.0, A, n, B, n, C, n, cut, -1, true); });
+      snprintf(nm, sizeof nm, "syrk<64> cols [0,%d) || syrk<128> cols [%d,%d)", cut, cut, tiles);
+      wall(nm, [&] {
+        syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, cut, true);
+        syrk_mirror(ctx2, n, 128, -1.0, A, n, B, n, C, n, cut, -1, false); });
+    }
+    wall("syrk<128> cols [0,t/4) || syrk<128> rest", [&] {
+      syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, tiles / 4, false);
+      syrk_mirror(ctx2, n, 128, -1.0, A, n, B, n, C, n, tiles / 4, -1, false); });
+    wall("syrk_mirror<128> alone", [&] { syrk_mirror(ctx, n, 128, -1.0, A, n, B, n, C, n, 0, -1, false); });
   }
   const int64_t q = 8192;
   if (n * n < 3 * q * q) return 0;
