@@ -1801,7 +1801,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int64_t nmail = 2 * maxb * 2 * S2_B;   // pq_resident: 2 buffers x workgroups x 64 word pairs
     const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N + nmail;
     const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
-    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + 2 * N /*taus1, scales1*/ +
+    const int64_t nfpart = (N / (S1F_CHUNKS * S2_B) + 3) * S2_B * S2_B;   // partial V'Y blocks of the fused small products
+    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + nfpart + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
     BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p2));
     double* q = (double*)p2;
@@ -1817,6 +1818,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemsetAsync(s1.mail, 0, nmail * sizeof(double), st));
     BK_HIP(hipMemsetAsync(s1.err, 0, sizeof(int), st));
     s1.Tall = q; q += ntall;
+    s1.fpart = q; q += nfpart;
     taus1 = q; q += 2 * N;
     AB = q; q += (int64_t)S2_LD * N;
     d_soff = (int64_t*)q;
