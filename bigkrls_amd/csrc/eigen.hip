@@ -1416,29 +1416,54 @@ __global__ void bt_extract_panel(const double* __restrict__ W, int n, int j0, in
 __global__ __launch_bounds__(256) void bt_build_t(const double* __restrict__ G, int pw,
                                                   const double* __restrict__ tau,
                                                   double* __restrict__ T) {
-  // column i of T needs columns 0..i-1: pw dependent steps; inside a step row r of the
-  // triangular product is shared by 4 lanes (k strided by 4) and folded with two shuffles
-  __shared__ double sT[TRD_NB * (TRD_NB + 1)];   // row-major with a padded stride: sT[r][k]
-  __shared__ double sG[TRD_NB * TRD_NB];
-  __shared__ double stau[TRD_NB];
-  constexpr int LT = TRD_NB + 1;
+  // Blocked recurrence: the four 16 x 16 diagonal blocks of T are built at the same time (one wave
+  // each, 16 dependent column steps: T[0:i, i] = -tau_i T[0:i,0:i] G[0:i, i] inside the block),
+  // then block column j = 1, 2, 3 follows from T(0:16j, j) = -T(0:16j, 0:16j) G(0:16j, j) T_jj
+  // (two small products each): 16 + 6 barriers instead of 64 steps with 16-deep dependent sums.
+  constexpr int NB = TRD_NB, LT = TRD_NB + 1, BB = 16;
+  __shared__ double sT[NB * LT];   // sT[r][k]
+  __shared__ double sG[NB * LT];   // sG[k][i] = v_k' v_i
+  __shared__ double sX[(NB - BB) * (BB + 1)];
+  __shared__ double stau[NB];
   const int t = threadIdx.x;
-  for (int e = t; e < TRD_NB * LT; e += 256) sT[e] = 0.0;
-  for (int e = t; e < pw * pw; e += 256) sG[e] = G[e];   // one batch of global loads
-  if (t < pw) stau[t] = tau[t];
+  for (int e = t; e < NB * LT; e += 256) { sT[e] = 0.0; sG[e] = 0.0; }
+  if (t < NB) stau[t] = (t < pw) ? tau[t] : 0.0;
   __syncthreads();
-  const int r = t >> 2, part = t & 3;
-  for (int i = 0; i < pw; ++i) {
-    const double ti = stau[i];
-    // T[0:i, i] = -tau_i * T[0:i,0:i] * G[0:i, i]   (row r only has entries k >= r)
-    double acc = 0.0;
-    if (r < i)
-      for (int k = r + part; k < i; k += 4) acc += sT[r * LT + k] * sG[k + i * pw];
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) {
-      if (r < i) sT[r * LT + i] = -ti * acc;
-      else if (r == i) sT[i * LT + i] = ti;
+  for (int e = t; e < pw * pw; e += 256) sG[(e % pw) * LT + (e / pw)] = G[e];   // one batch of global loads
+  __syncthreads();
+  {
+    const int w = t >> 6, lane = t & 63, rl = lane >> 2, part = lane & 3;
+    const int c0 = BB * w, r = c0 + rl;
+    for (int ii = 0; ii < BB; ++ii) {
+      const int i = c0 + ii;
+      const double ti = stau[i];
+      double acc = 0.0;
+      if (rl < ii)
+        for (int k = r + part; k < i; k += 4) acc += sT[r * LT + k] * sG[k * LT + i];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0) {
+        if (rl < ii) sT[r * LT + i] = -ti * acc;
+        else if (rl == ii) sT[i * LT + i] = ti;
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = 1; j < NB / BB; ++j) {
+    const int R = BB * j, cj = BB * j;
+    for (int e = t; e < R * BB; e += 256) {       // X = G(0:R, j) T_jj
+      const int r = e >> 4, c = e & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < BB; ++k) acc += sG[r * LT + cj + k] * sT[(cj + k) * LT + cj + c];
+      sX[r * (BB + 1) + c] = acc;
+    }
+    __syncthreads();
+    for (int e = t; e < R * BB; e += 256) {       // T(0:R, j) = -T(0:R, 0:R) X
+      const int r = e >> 4, c = e & 15;
+      double acc = 0.0;
+      for (int k = r; k < R; ++k) acc += sT[r * LT + k] * sX[k * (BB + 1) + c];
+      sT[r * LT + cj + c] = -acc;
     }
     __syncthreads();
   }
