@@ -413,11 +413,20 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, doub
 __global__ void splitk_reduce_kernel(const double* __restrict__ partial, int splits, int M, int N,
                                      double alpha, double beta, double* __restrict__ C,
                                      int64_t ldc) {
+  // slabs are summed in the fixed order z = 0, 1, ... (deterministic); the loads of four slabs are
+  // issued together -- with one load in flight per thread the kernel is latency-bound
   const int64_t total = (int64_t)M * N;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
+    const double* p = partial + e;
     double s = 0.0;
-    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * total + e];
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      const double a0 = p[(int64_t)(z + 0) * total], a1 = p[(int64_t)(z + 1) * total];
+      const double a2 = p[(int64_t)(z + 2) * total], a3 = p[(int64_t)(z + 3) * total];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; z < splits; ++z) s += p[(int64_t)z * total];
     const int m = (int)(e % M), n = (int)(e / M);
     const int64_t o = (int64_t)m + (int64_t)n * ldc;
     C[o] = (beta == 0.0) ? alpha * s : alpha * s + beta * C[o];
