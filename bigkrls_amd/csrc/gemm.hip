@@ -578,6 +578,43 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   const int lm = lane & 15, lk = lane >> 4;
   double* buf = smem + wave * (16 * 17);
   const bool diag_tile = (tm == p);
+  if (!diag_tile && m0 + BM <= M) {
+    // Interior tile (all 128 rows inside, strictly below the diagonal): no predicates. A predicated
+    // load or store sits in its own basic block and the compiler waits for memory before each of
+    // them, which serialises the whole read-modify-write (16 dependent HBM round trips per strip).
+    const double* cb = C + (int64_t)(m0 + wm + lm) + (int64_t)(n0 + wn + lk) * ldc;   // lane's element of sub-tile (0, 0)
+    double* cw = C + (int64_t)(m0 + wm + lm) + (int64_t)(n0 + wn + lk) * ldc;
+    double* mw = C + (int64_t)(n0 + wn + lm) + (int64_t)(m0 + wm + lk) * ldc;         // its mirror image
+    auto load_int = [&](int j, d4 (&cold)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[i][r] = cb[i * 16 + (int64_t)(j * 16 + 4 * r) * ldc];
+    };
+    d4 cbuf[2][4];
+    load_int(0, cbuf[0]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) load_int(j + 1, cbuf[(j + 1) & 1]);
+      d4 (&cold)[4] = cbuf[j & 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vv[r] = cold[i][r] + alpha * acc[i][j][r];
+          cw[i * 16 + (int64_t)(j * 16 + 4 * r) * ldc] = vv[r];
+          buf[(lk + 4 * r) * 17 + lm] = vv[r];   // buf[n_local][m_local]
+        }
+        double tv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[r] = buf[lm * 17 + (lk + 4 * r)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw[j * 16 + (int64_t)(i * 16 + 4 * r) * ldc] = tv[r];
+      }
+    }
+    return;
+  }
   // C is fetched one 64 x 16 column strip at a time, one strip ahead of the stores (vmcnt is
   // in-order over loads and stores: loads issued after a strip's stores would wait for them).
   auto load_strip = [&](int j, d4 (&cold)[4]) {
