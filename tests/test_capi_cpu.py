@@ -95,3 +95,27 @@ def test_summary_student_t_tail_matches_scipy():
         for t in (0.0, 1e-3, 0.5, 1.96, 5.0, 12.0, 40.0):
             a, b = api._pt_upper(t, df), stats.t.sf(t, df)
             assert abs(a - b) <= 1e-7 * b + 1e-300, (t, df, a, b)
+
+
+def test_column_major_filler_matches_fortran_flattening():
+    """Host side of Context.from_numpy: pieces of the column-major flattening of a 2-D array of any
+    layout (C, Fortran, strided view), as the pinned staging buffer receives them."""
+    from bigkrls_amd.device import _column_major_filler
+    rng = np.random.default_rng(0)
+    for shape in [(7, 5), (1, 9), (9, 1), (64, 3), (5, 0)]:
+        for order in "CF":
+            a = np.asarray(rng.random(shape), order=order)
+            ref = a.reshape(-1, order="F")
+            fill = _column_major_filler(a)
+            for _ in range(40):
+                if ref.size == 0:
+                    break
+                off = int(rng.integers(0, ref.size))
+                m = int(rng.integers(1, ref.size - off + 1))
+                dst = np.full(m, -1.0)
+                fill(dst, off, m)
+                assert np.array_equal(dst, ref[off:off + m]), (shape, order, off, m)
+    view = rng.random((12, 10))[::2, 1:7]
+    dst = np.empty(view.size)
+    _column_major_filler(view)(dst, 0, view.size)
+    assert np.array_equal(dst, view.reshape(-1, order="F"))
