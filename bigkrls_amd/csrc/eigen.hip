@@ -1823,7 +1823,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int64_t nb64 = N * S2_B;
     void *p2 = nullptr, *pvv = nullptr;
     const int64_t maxb = (N + 255) / 256 + 2;
-    const int64_t nmail = 2 * maxb * 2 * S2_B;   // pq_resident: 2 buffers x workgroups x 64 word pairs
+    const int64_t nmail1 = 2 * maxb * 2 * S2_B;  // pq_resident: 2 buffers x workgroups x 64 word pairs
+    const int64_t nmail = nmail1 + 2 * 16 * 2 * S2_B;   // + 2 buffers x 16 group boxes
     const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N + nmail;
     const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
     const int64_t nfpart = (N / (S1F_CHUNKS * S2_B) + 3) * S2_B * S2_B;   // partial V'Y blocks of the fused small products
@@ -1839,6 +1840,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     s1.small = q; q += 8 * S2_B * S2_B;
     s1.part = q; q += npart;
     s1.mail = s1.part + (npart - nmail);
+    s1.mail2 = s1.mail + nmail1;
     s1.err = (int*)scratch;
     BK_HIP(hipMemsetAsync(s1.mail, 0, nmail * sizeof(double), st));
     BK_HIP(hipMemsetAsync(s1.err, 0, sizeof(int), st));

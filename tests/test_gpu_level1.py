@@ -442,3 +442,25 @@ def test_eigen_back_transform_variants(lib, monkeypatch, n):
     assert np.max(np.abs(out["wy"][0] - out["seq"][0])) / out["wy"][0][0] < 1e-13
     # well separated top of the spectrum: the vectors themselves agree
     assert np.max(np.abs(np.abs(out["wy"][1][:, :5]) - np.abs(out["seq"][1][:, :5]))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_eigen_large_panels_two_level_exchange(ctx):
+    """n = 7700: the first stage-1 panels span 30 workgroups, above the threshold where the
+    register-resident panel QR switches from the all-to-all of partial sums to the two-level exchange
+    (group leaders, then group sums). Top eigenpairs: residual, orthogonality, trace."""
+    from bigkrls_amd import ops
+    n, p, k = 7700, 5, 48
+    X, _ = orc.synth(n, p, 61)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    eo = ops.bEigen(K, None, 0.0)                       # all eigenvalues ...
+    assert abs(eo.values.sum() - n) / n < 1e-12         # ... sum to trace(K) = n
+    top = ops.bEigen(K, k, -1.0)
+    Q = top.vectors
+    lam = top.values[:k]
+    assert np.max(np.abs(lam - eo.values[:k])) / lam[0] < 1e-13
+    R = ops.gemm(False, False, K, Q).to_numpy() - Q.to_numpy() * lam
+    G = ops.gemm(True, False, Q, Q).to_numpy()
+    assert np.max(np.abs(R)) / lam[0] < 1e-12
+    assert np.max(np.abs(G - np.eye(k))) < 1e-11
