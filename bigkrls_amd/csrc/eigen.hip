@@ -513,6 +513,82 @@ struct MergeDesc {
   double rho;
 };
 
+// Leaves of the divide & conquer tree (17..32 rows when n > 64): implicit QL with eigenvectors
+// (EISPACK tql2 / "tqli"), one wave per leaf. Every lane runs the same scalar recurrence on d, e in
+// LDS (identical values, so the redundant stores are harmless) and lane r applies the rotations to
+// row r of the eigenvector block. Replaces the five lowest merge levels (of ~1 ms of launches, copies
+// and synchronisations each) by one launch.
+constexpr int DC_LEAF = 32;
+__global__ __launch_bounds__(64) void dc_leaf_ql(const int2* __restrict__ leaves, const double* __restrict__ dd,
+                                                 const double* __restrict__ ee, double* __restrict__ Q0,
+                                                 double* __restrict__ Q1, int64_t ld,
+                                                 double* __restrict__ lam_out, int* __restrict__ fail) {
+  __shared__ double sd[DC_LEAF], se[DC_LEAF + 1], sZ[DC_LEAF][DC_LEAF + 1];
+  const int2 lf = leaves[blockIdx.x];
+  const int s = lf.x, m = lf.y, lane = threadIdx.x;
+  if (lane < m) {
+    sd[lane] = dd[s + lane];
+    se[lane] = (lane < m - 1) ? ee[s + lane] : 0.0;
+    for (int c = 0; c < m; ++c) sZ[lane][c] = (c == lane) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dsum = fabs(sd[mm]) + fabs(sd[mm + 1]);
+        if (fabs(se[mm]) <= DEPS * dsum) break;
+      }
+      if (mm != l) {
+        if (++iter > 80) {          // no convergence: reported, never silently accepted
+          if (lane == 0) *fail = 1;
+          break;
+        }
+        double g = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
+        double r = hypot(g, 1.0);
+        g = sd[mm] - sd[l] + se[l] / (g + copysign(r, g));
+        double sn = 1.0, cs = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          const double f = sn * se[i], b = cs * se[i];
+          r = hypot(f, g);
+          se[i + 1] = r;
+          if (r == 0.0) {
+            sd[i + 1] -= p;
+            se[mm] = 0.0;
+            break;
+          }
+          sn = f / r;
+          cs = g / r;
+          g = sd[i + 1] - p;
+          r = (sd[i] - g) * sn + 2.0 * cs * b;
+          p = sn * r;
+          sd[i + 1] = g + p;
+          g = cs * r - b;
+          if (lane < m) {
+            const double zf = sZ[lane][i + 1], zi = sZ[lane][i];
+            sZ[lane][i + 1] = sn * zi + cs * zf;
+            sZ[lane][i] = cs * zi - sn * zf;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        sd[l] -= p;
+        se[l] = g;
+        se[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  __syncthreads();
+  if (lane < m) {
+    lam_out[s + lane] = sd[lane];
+    for (int c = 0; c < m; ++c) {
+      const double v = sZ[lane][c];
+      Q0[(int64_t)(s + lane) + (int64_t)(s + c) * ld] = v;
+      Q1[(int64_t)(s + lane) + (int64_t)(s + c) * ld] = v;
+    }
+  }
+}
+
 __global__ void dc_init_identity(double* __restrict__ Q, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) Q[(int64_t)i * n + i] = 1.0;
@@ -907,6 +983,9 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   hipStream_t st = ctx->stream;
   const int64_t N = n;
   // ---- tree -----------------------------------------------------------------
+  // (BIGKRLS_DCLEAF=1: tear down to 1 x 1 leaves, no QL leaf solver)
+  const char* leaf_env = getenv("BIGKRLS_DCLEAF");
+  const int leaf_max = (n > 2 * DC_LEAF && !(leaf_env && std::string(leaf_env) == "1")) ? DC_LEAF : 1;
   std::vector<Node> nodes;
   nodes.reserve(2 * n);
   std::vector<double> dadj = hd;
@@ -924,7 +1003,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       if (it.parent >= 0) {
         if (it.side == 0) nodes[it.parent].left = id; else nodes[it.parent].right = id;
       }
-      if (it.m > 1) {
+      if (it.m > leaf_max) {
         const int n1 = it.m / 2;
         const int cut = it.s + n1 - 1;  // e[cut] couples rows cut, cut+1
         const double rho = std::fabs(he[cut]);
@@ -942,7 +1021,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   }
   std::vector<std::vector<int>> by_depth(maxdepth + 1);
   for (int id = 0; id < (int)nodes.size(); ++id)
-    if (nodes[id].m > 1) by_depth[nodes[id].depth].push_back(id);
+    if (nodes[id].left >= 0) by_depth[nodes[id].depth].push_back(id);
 
   // ---- device state ---------------------------------------------------------
   BK_HIP(hipMemsetAsync(Q0, 0, (size_t)N * N * sizeof(double), st));
@@ -990,6 +1069,38 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   A.dlam.resize(n); A.w.resize(n);
   A.rowpos.resize(n); A.pole_of_row.resize(n); A.srccol.resize(n); A.cpos.resize(n);
   A.defsrc.resize(n); A.defdst.resize(n);
+
+  // ---- leaves larger than 1 x 1: QL on the device, eigenvector blocks into both copies of Q --------
+  if (leaf_max > 1) {
+    const auto t_leaf = std::chrono::steady_clock::now();
+    std::vector<int> lf;   // (s, m) pairs
+    for (const Node& nd : nodes)
+      if (nd.left < 0 && nd.m > 1) { lf.push_back(nd.s); lf.push_back(nd.m); }
+    const int nleaf = (int)lf.size() / 2;
+    if (nleaf > 0) {
+      int* d_fail = d_iota;                        // (d_iota is filled later, only on the factored path)
+      BK_HIP(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+      BK_HIP(hipMemcpyAsync(d_dlam, dadj.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_w, he.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+      BK_HIP(hipMemcpyAsync(d_rowpos, lf.data(), lf.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(dc_leaf_ql, dim3(nleaf), dim3(64), 0, st, (const int2*)d_rowpos, (const double*)d_dlam,
+                         (const double*)d_w, Q0, Q1, N, d_lam, d_fail);
+      BK_CHECK_LAUNCH();
+      int h_fail = 0;
+      BK_HIP(hipMemcpyAsync(hlam.data(), d_lam, n * sizeof(double), hipMemcpyDeviceToHost, st));
+      BK_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+      BK_HIP(hipStreamSynchronize(st));
+      if (h_fail != 0) {
+        set_error("eigen: the QL iteration of a divide & conquer leaf did not converge");
+        return BIGKRLS_ENOCONV;
+      }
+      for (Node& nd : nodes)
+        if (nd.left < 0 && nd.m > 1) nd.dv.assign(hlam.begin() + nd.s, hlam.begin() + nd.s + nd.m);
+    }
+    if (getenv("BIGKRLS_VERBOSE"))
+      fprintf(stderr, "[bigkrls]   d&c leaves: %6d of up to %d rows (QL) %8.2f ms\n", nleaf, leaf_max,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_leaf).count());
+  }
 
   int64_t nv_final = 0;
   const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
