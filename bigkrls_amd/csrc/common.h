@@ -127,7 +127,7 @@ int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doubl
 // tile columns [tn_begin, tn_end) of the lower tile triangle only (tn_end < 0: all of them)
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                 const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin = 0,
-                int tn_end = -1, bool narrow_tiles = false);
+                int tn_end = -1, bool narrow_tiles = false, bool skip_first_column = false);
 int side_stream_get(bigkrls_ctx* ctx);
 // raise a kernel's dynamic shared-memory limit once per context (device)
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes);

@@ -671,12 +671,15 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
 
 template <int SBN>
 static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, double* C, int64_t ldc,
-                              int tiles, int tn_begin, int tn_end) {
+                              int tiles, int tn_begin, int tn_end, bool skip_first_column = false) {
   constexpr int CPT = 128 / SBN;
   // tile columns of one 128-wide group q share the first row tile q: the group starts at
   // CPT * (q tiles - q(q-1)/2)
   auto first_of = [&](int64_t q) { return CPT * (q * tiles - q * (q - 1) / 2); };
-  const int64_t t0 = first_of(tn_begin), nt = first_of(tn_end) - t0;
+  // (skip_first_column: the first SBN-wide tile column of group tn_begin, tiles - tn_begin tiles, was
+  //  updated by the caller)
+  const int64_t t0 = first_of(tn_begin) + (skip_first_column ? tiles - tn_begin : 0), nt = first_of(tn_end) - t0;
+  if (nt <= 0) return BIGKRLS_OK;
   BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN>, smem_bytes(SBN)));
   hipLaunchKernelGGL(syrk_mirror_kernel<SBN>, dim3((unsigned)nt), dim3(NT), smem_bytes(SBN), ctx->stream, g,
                      alpha, C, ldc, tiles, (int)t0);
@@ -686,7 +689,7 @@ static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double al
 
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                 const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin, int tn_end,
-                bool narrow_tiles) {
+                bool narrow_tiles, bool skip_first_column) {
   if (m <= 0 || k <= 0) return BIGKRLS_OK;
   BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror: dimension too large");
   GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
@@ -695,7 +698,8 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
   if (tn_begin >= tn_end) return BIGKRLS_OK;
   // 128 x 64 tiles (three workgroups per CU) share the GPU better with a concurrent
   // register-resident panel QR; alone, 128 x 128 tiles are ~6 % faster (N = 20 000: 1.65 vs 1.76 ms)
-  if (narrow_tiles) return launch_syrk_mirror<64>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
+  BK_REQUIRE(!skip_first_column || narrow_tiles, "syrk_mirror: skip_first_column needs 64-wide tiles");
+  if (narrow_tiles) return launch_syrk_mirror<64>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end, skip_first_column);
   return launch_syrk_mirror<128>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
 }
 
