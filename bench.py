@@ -255,7 +255,8 @@ def main():
             mfma_entry("band_update", "syrk_mirror_kernel: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
                        "store (stage 1 of the two-stage tridiagonalisation), one launch per 64-column panel",
                        "achieved = m(m+1)*2b algorithmic flops per launch (lower triangle incl. diagonal tiles, "
-                       "m = trailing size, b = 64) / HIP-event duration on the launch stream; traffic = algorithmic "
+                       "b = 64, m = trailing size minus the next panel's 64 columns, which the preceding fused "
+                       "kernel s1_fused_z updates) / HIP-event duration on the launch stream; traffic = algorithmic "
                        "HBM bytes of the launch (read 4 m^2 + write 8 m^2) x the FETCH_SIZE+WRITE_SIZE / algorithmic "
                        "ratio of profiles/r01_traffic_pmc.json (1.011)",
                        traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel"), 0))
