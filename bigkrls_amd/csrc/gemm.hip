@@ -449,11 +449,14 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
   int splits = 1;
   if (ntile < 512 && g.K >= 1024) {
     const int maxs = std::min(64, std::max(1, g.K / 256));
+    // rough time model in us: a k-step of a workgroup ~0.06 us per unit of K; per split the partial
+    // slab is written and read again (16 bytes per output element at ~5 TB/s) plus a fixed ~0.2 us
+    const double per_split = 3.2e-6 * (double)g.M * (double)g.N + 0.2;
     double best = 1e30;
     for (int sp = 1; sp <= maxs; ++sp) {
       const int rounds = (ntile * sp + 511) / 512;
-      const double cost = (double)rounds / sp + 0.004 * sp;
-      if (cost < best - 1e-12) { best = cost; splits = sp; }
+      const double cost = 0.06 * rounds * ((double)g.K / sp) + per_split * sp;
+      if (cost < best - 1e-9) { best = cost; splits = sp; }
     }
   }
   int k_chunk = ((g.K + splits - 1) / splits + BK - 1) / BK * BK;
