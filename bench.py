@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- the bigKRLS() fit on MI355X, BASELINE.json's metric and config.
+"""bench.py -- the bigKRLS() fit on MI355X, BASELINE.json's metric and configs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
 
 A step = one full bigKRLS() fit (kernel -> eigen -> lambda search -> coefficients ->
-variance matrices -> marginal effects) of configs[2]: N=20000, P=20, fp64,
-eigtrunc=0.001, synthetic G(N,P,seed=103) inputs already resident in HBM when the
-timed region starts (the N x P input is 3.2 MB; the PCIe-inclusive figure is in
-DESIGN.md).  Rank 0 prints ONE JSON line.  For N > 1 the same fit is row-block
+variance matrices -> marginal effects). The default workload is configs[2] (C3), the
+one BASELINE.json's metric is quoted on: N=20000, P=20, fp64, eigtrunc=0.001, synthetic
+G(N,P,seed=103) inputs already resident in HBM when the timed region starts (the N x P
+input is 3.2 MB; the PCIe-inclusive figure is in DESIGN.md). `--config` selects another
+BASELINE.json configuration (C2 N=5000 P=10; C4 N=50000 P=20 Neig=512; C5 N=100000 P=50
+Neig=1024 which.derivatives=c(1,3,5)); --n/--p/--seed/--neig/--eigtrunc/--which-derivatives
+override single fields. Rank 0 prints ONE JSON line. For N > 1 the same fit is row-block
 partitioned over the ranks (strong scaling): see bigkrls_amd/dist.py.
 
-`roofline` is for the dominant kernel of the fit -- whichever of the profiled
-eigensolver kernels (the stage-1 band update / A22 V GEMMs, bulge chasing, or the
-one-stage symv) takes the most time on the critical path -- measured live with HIP
-events on the launch stream; the panel QR, which runs concurrently on the look-ahead
-stream, is listed in `other_kernels`; `kernel_gemm` reports the Gaussian-kernel GEMM
-the metric names.
-`cpu_baseline` times the oracle's literal restatement of the reference on the
-host cores on a bounded sample (rank 0, N=1 only).
+`roofline` is for the dominant kernel of the fit -- whichever of the profiled kernels takes
+the most time on the critical path (dense path: the stage-1 band update / A22 V GEMMs, bulge
+chasing, or the one-stage symv; Neig << N: the K B_j product of the block Lanczos) --
+measured live with HIP events on the launch stream; the panel QR, which runs concurrently
+on the look-ahead stream, is listed in `other_kernels`; `kernel_gemm` reports the
+Gaussian-kernel GEMM the metric names.
+`cpu_baseline` times the oracle's literal restatement of the reference on the host cores at
+the bench size (oracle/cpu_baseline.py, a child process started before the GPU is touched
+and released after the GPU timing; rank 0, N=1 only), bounded by --cpu-budget-s.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,18 +37,51 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 64 cyc)
 
+# BASELINE.json configs[1..4] (configs[0], C1, is the CPU-only plumbing case: tests/, not a bench line)
+CONFIGS = {
+    "C2": dict(n=5000, p=10, seed=102, neig=None, eigtrunc=None, which=None,
+               desc="N=5000 P=10 fp64, full eigendecomp + all derivatives"),
+    "C3": dict(n=20000, p=20, seed=103, neig=None, eigtrunc=None, which=None,
+               desc="N=20000 P=20 fp64, eigtrunc=0.001"),
+    "C4": dict(n=50000, p=20, seed=104, neig=512, eigtrunc=None, which=None,
+               desc="N=50000 P=20 fp64, Neig=512"),
+    "C5": dict(n=100000, p=50, seed=105, neig=1024, eigtrunc=None, which=[1, 3, 5],
+               desc="N=100000 P=50 fp64, Neig=1024, which.derivatives subset"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=20000)
-    ap.add_argument("--p", type=int, default=20)
-    ap.add_argument("--seed", type=int, default=103)
-    ap.add_argument("--cpu-n", type=int, default=2000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--p", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--neig", type=int, default=None)
+    ap.add_argument("--eigtrunc", type=float, default=None)
+    ap.add_argument("--which-derivatives", type=str, default=None,
+                    help="comma-separated 1-based columns, e.g. 1,3,5")
+    ap.add_argument("--cpu-n", type=int, default=None,
+                    help="rows of the CPU-baseline sample (default: the bench N for C2/C3)")
+    ap.add_argument("--cpu-budget-s", type=float, default=900.0,
+                    help="wall-clock bound of the CPU baseline; what is measured until then is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    custom = False
+    for key, val in (("n", args.n), ("p", args.p), ("seed", args.seed), ("neig", args.neig),
+                     ("eigtrunc", args.eigtrunc)):
+        if val is not None:
+            custom = custom or cfg[key] != val
+            cfg[key] = val
+    if args.which_derivatives is not None:
+        cfg["which"] = [int(t) for t in args.which_derivatives.split(",") if t]
+        custom = True
+    cfg["name"] = args.config + ("*" if custom else "")
+    args.cfg = cfg
+    return args
 
 
 def symv_traffic(alg_bytes_total, launches):
@@ -68,45 +107,111 @@ def pmc_ratio(kernel):
         return None
 
 
-def cpu_baseline(p, n_cpu, seed):
-    """Literal CPU restatement (oracle, kind 'port') of the same fit on a bounded sample."""
-    import numpy as np
-    from oracle import krls_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    X, y = orc.synth(n_cpu, p, seed)
-    T = {}
-    t0 = time.perf_counter()
-    orc.fit(y, X, literal=True, timings=T, return_squares=False)
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.fit(y, X, literal=False, return_squares=False)
-    dt_fast = time.perf_counter() - t0
-    return {
-        "value": round(dt, 3), "unit": "s per fit", "cores": int(threads), "kind": "port",
-        # the same fit with the O(N^2 K) identities the HIP path uses (so that the speed-up is not
-        # inflated by the reference's avoidable N^3 terms), same host, same sample
-        "efficient_port_s": round(dt_fast, 3),
-        "sample": (f"full literal fit (reference loop structure: N^2K/2-per-probe solveforc, 4N^3 V_yhat, "
-                   f"4N^3-per-column derivatives; LAPACK dsyevd/BLAS via scipy OpenBLAS) at N={n_cpu}, "
-                   f"P={p}: 1/{(20000 // n_cpu) ** 3} of the N^3 work of the N=20000 workload; "
-                   f"hand loops single-threaded like the reference, BLAS threads={threads}"),
-        "phases_s": {k: round(v, 3) for k, v in T.items()},
-    }
+class CpuBaseline:
+    """oracle/cpu_baseline.py as a child process (kind "port": the oracle's literal restatement of
+    the reference). Started before this process touches the GPU -- a process that has initialised
+    the GPU must not spawn programs on the GPU boxes -- it waits on stdin until `release()` is called
+    after the GPU timing, so the two never share the host cores. `collect()` waits until the child is
+    done or the budget is spent (then the child, this exact PID, is killed) and assembles the
+    `cpu_baseline` object from the phases measured until then."""
+
+    def __init__(self, n, p, seed, eigtrunc, small_n=2000):
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--p", str(p),
+               "--seed", str(seed), "--small-n", str(small_n)]
+        if eigtrunc is not None:
+            cmd += ["--eigtrunc", str(eigtrunc)]
+        self.n, self.p = n, p
+        self.lines = []
+        self.proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+        self.reader = threading.Thread(target=self._read, daemon=True)
+        self.reader.start()
+
+    def _read(self):
+        for line in self.proc.stdout:
+            line = line.strip()
+            if line.startswith("{"):
+                try:
+                    self.lines.append(json.loads(line))
+                except ValueError:
+                    pass
+
+    def release(self):
+        try:
+            self.proc.stdin.write("go\n")
+            self.proc.stdin.flush()
+        except Exception:
+            pass
+        self.t_go = time.perf_counter()
+
+    def abandon(self):
+        if self.proc.poll() is None:
+            self.proc.kill()
+
+    def collect(self, budget_s):
+        try:
+            self.proc.wait(timeout=max(1.0, budget_s))
+            timed_out = False
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+            self.proc.wait()
+            timed_out = True
+        self.reader.join(timeout=5.0)
+        ph = {d["phase"]: d for d in self.lines if "phase" in d}
+        cores = ph.get("ready", {}).get("cores", os.cpu_count() or 1)
+        small = ph.get("small")
+        res = {"unit": "s per fit", "cores": int(cores), "kind": "port"}
+        lit_keys = ["kernel", "eigen", "lambda", "coeffs", "vcov_c", "vcov_fitted", "derivatives"]
+        if "done" in ph:
+            d = ph["done"]
+            res.update({
+                "value": d["literal_s"],
+                "extrapolated": True,
+                "efficient_port_s": d["efficient_s"],
+                "sample": (f"literal restatement of the reference at the bench size N={self.n}, P={self.p} "
+                           f"(BLAS/LAPACK threads = {cores}; hand loops single-threaded like the reference): kernel "
+                           "row loop, dsyevd and V in full; lambda search = one literal solveforc probe x "
+                           f"{d['probes']} probes; V_yhat (4N^3) and one derivative column's L'VL (4N^3) on N/20 "
+                           f"columns x 20, the column then x P={self.p} (all three marked extrapolated); "
+                           f"efficient_port_s = the O(N^2 K) identities in full at N={self.n}"),
+                "phases_s": {k: ph[k]["s"] for k in lit_keys if k in ph},
+                "extrapolated_phases": [k for k in lit_keys if ph.get(k, {}).get("extrapolated")],
+                "efficient_phases_s": d["efficient_phases_s"],
+                "lastkeeper": d["lastkeeper"], "lambda": d["lam"],
+            })
+        else:
+            got = {k: ph[k]["s"] for k in lit_keys if k in ph}
+            res.update({
+                "value": small["literal_s"] if small else None,
+                "extrapolated": False,
+                "efficient_port_s": small["efficient_s"] if small else None,
+                "sample": (f"the N={self.n} sample did not finish within the {budget_s:.0f} s budget"
+                           f"{' (killed)' if timed_out else ''}; phases measured at N={self.n} until then are in "
+                           f"partial_phases_s; value = the full literal fit at N={small['n'] if small else '?'}, "
+                           f"P={self.p} (BLAS threads = {cores})"),
+                "partial_phases_s": got,
+            })
+        if small:
+            res["small_sample"] = {"n": small["n"], "literal_s": small["literal_s"],
+                                   "efficient_s": small["efficient_s"], "phases_s": small["phases_s"]}
+        return res
 
 
 def main():
     args = parse()
+    cfg = args.cfg
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- CPU-baseline child: started before anything here touches the GPU ------------------------
+    cpu = None
+    cpu_n = args.cpu_n if args.cpu_n is not None else (cfg["n"] if cfg["n"] <= 20000 else None)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and cpu_n is not None:
+        cpu = CpuBaseline(cpu_n, cfg["p"], cfg["seed"], cfg["eigtrunc"])
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -118,20 +223,44 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
+    try:
+        res = run(args, cfg, world, rank, local_rank, np, torch, dist)
+    except BaseException:
+        if cpu is not None:
+            cpu.abandon()
+        raise
+    if rank == 0:
+        if cpu is not None:
+            cpu.release()
+            res["cpu_baseline"] = cpu.collect(args.cpu_budget_s)
+        elif world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = {
+                "value": None, "unit": "s per fit", "cores": os.cpu_count(), "kind": "port",
+                "sample": (f"not timed at N={cfg['n']}: the literal CPU path is infeasible at this size (dsyevd of a "
+                           f"{8e-9 * cfg['n'] ** 2:.0f} GB matrix, hours; SURVEY.md section 8(d)); pass --cpu-n to time "
+                           "the restatement on a smaller sample of the same generator")}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args, cfg, world, rank, local_rank, np, torch, dist):
     import bigkrls_amd as bk
     from bigkrls_amd.synth import synth
 
     ctx = bk.Context(local_rank if world > 1 else 0)
-    X, y = synth(args.n, args.p, args.seed)
+    n, p = cfg["n"], cfg["p"]
+    X, y = synth(n, p, cfg["seed"])
+    fit_kw = dict(Neig=cfg["neig"], eigtrunc=cfg["eigtrunc"], which_derivatives=cfg["which"])
 
     if world > 1:
         from bigkrls_amd import dist as bkdist
 
         def one_fit(timings):
-            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=False)
+            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=False, **fit_kw)
     else:
         def one_fit(timings):
-            return bk.bigKRLS(y, X, ctx=ctx, timings=timings)
+            return bk.bigKRLS(y, X, ctx=ctx, timings=timings, **fit_kw)
 
     def barrier():
         if world > 1:
@@ -161,17 +290,18 @@ def main():
     sec_per_fit = dt / args.steps
 
     prof = {name: ctx.get_profile(name) for name in
-            ("symv", "kernel_block", "trailing_update", "band_update", "band_av", "bulge_chase", "panel_qr")}
+            ("symv", "kernel_block", "trailing_update", "band_update", "band_av", "bulge_chase", "panel_qr",
+             "lanczos_kb", "lanczos_cgs2")}
     ctx.set_profile(False)
 
+    res = None
     if rank == 0:
-        n, p = args.n, args.p
         phases = {k: round(v / args.steps, 4) for k, v in phase_sum.items()}
         kb_ms, kb_flops, kb_n = prof["kernel_block"]
 
         STRIDE = 8   # the library brackets every 8th stage-1 panel (S1_PROF_STRIDE): totals are x8
 
-        def mfma_entry(name, kernel, note, traffic=None):
+        def mfma_entry(name, kernel, note, traffic=None, stride=STRIDE):
             ms, fl, cnt = prof[name]
             if ms <= 0:
                 return None
@@ -180,9 +310,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic(fl / max(cnt, 1)) if traffic else None,
                     "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
-                    "total_ms_per_fit": round(ms * STRIDE / args.steps, 2),
+                    "total_ms_per_fit": round(ms * stride / args.steps, 2),
                     "avg_algorithmic_flops_per_launch": round(fl / max(cnt, 1), 0),
-                    "note": note + "; every 8th panel is bracketed (total_ms_per_fit = 8 x the sampled time)"}
+                    "note": note + ("; every 8th panel is bracketed (total_ms_per_fit = 8 x the sampled time)"
+                                    if stride > 1 else "")}
 
         def symv_entry():
             ms, by, cnt = prof["symv"]
@@ -205,7 +336,7 @@ def main():
             if ms <= 0:
                 return None
             gbs = (by / 1e9) / (ms / 1e3)
-            resident = cnt <= args.steps          # one persistent launch per fit vs sampled wavefront launches
+            resident = ms * 1e3 / max(cnt, 1) > 1000.0   # one persistent launch per decomposition vs sampled ~10 us wavefront launches
             if resident:
                 return {"kernel": "bc_resident: LDS-resident bulge chasing (stage 2, band b=64 -> tridiagonal), one "
                                   "persistent launch per fit, one workgroup per band location",
@@ -217,7 +348,7 @@ def main():
                         "note": "achieved = algorithmic HBM bytes (band read once, 16 N b, + stored reflectors, "
                                 "4 N^2) / HIP-event duration. The band lives in LDS for the whole stage; the kernel "
                                 "is bound by the 2 message hops per sweep between neighbouring workgroups "
-                                "(N sweeps x ~6 us), not by HBM"}
+                                "(N sweeps x ~4.4 us), not by HBM"}
             return {"kernel": "bc_wavefront: one anti-diagonal wavefront of bulge-chasing tasks (stage 2 of the "
                               "two-stage tridiagonalisation, band b=64 -> tridiagonal), ~2N launches per fit",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -263,6 +394,13 @@ def main():
                        if pmc_ratio("syrk_mirror_kernel") else None),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
                        "achieved = 2 m^2 b flops per launch / HIP-event duration"),
+            mfma_entry("lanczos_kb", "gemm_kernel<N,N,128>: W = K B_j, the N x N x 128 product of one block-Lanczos "
+                       "step (Neig << N, the reference's eigs_sym branch src/eigen.cpp:18-22)",
+                       "achieved = 2 N^2 b flops (b = 128) per step / HIP-event duration on the launch stream, every "
+                       "step bracketed; reads K once per step (8 N^2 B, AI = 32 flop/B)", stride=1),
+            mfma_entry("lanczos_cgs2", "gemm_kernel<T,N> + gemm_kernel<N,N>: classical Gram-Schmidt twice against all "
+                       "earlier blocks (C = B'W, W -= B C), four skinny GEMMs per step",
+                       "achieved = 8 N dim b flops per step / HIP-event duration, every step bracketed", stride=1),
         ]
         cands = [c for c in cands if c]
         # The dominant kernel is the one with the most time on the critical path: pq_resident runs on
@@ -286,9 +424,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"C3: bigKRLS() full fit, N={n}, P={p}, fp64, Neig=N, eigtrunc=0.001, "
-                                   "all derivatives, vcov.est=TRUE; G(N,P,seed) = sin(X beta)+0.25 eps",
-                       "n": n, "p": p, "seed": args.seed, "lastkeeper": int(lastkeeper),
+            "config": {"workload": (f"{cfg['name']} ({cfg['desc']}): bigKRLS() full fit, N={n}, P={p}, fp64, "
+                                    f"Neig={'N' if cfg['neig'] is None else cfg['neig']}, "
+                                    f"eigtrunc={cfg['eigtrunc'] if cfg['eigtrunc'] is not None else (0.001 if n > 3000 else 0)}, "
+                                    f"{'all derivatives' if cfg['which'] is None else 'which.derivatives=' + str(cfg['which'])}, "
+                                    "vcov.est=TRUE; G(N,P,seed) = sin(X beta)+0.25 eps"),
+                       "name": cfg["name"], "n": n, "p": p, "seed": cfg["seed"], "neig": cfg["neig"],
+                       "which_derivatives": cfg["which"], "lastkeeper": int(lastkeeper),
                        "lambda": float(lam),
                        "parallelism": "1 GPU" if world == 1 else f"row-block x{world}, RCCL all-gather"},
             "phases_s": phases,
@@ -302,18 +444,14 @@ def main():
                 "traffic": (round(8.0 * n * n * pmc_ratio("kernel_block_sym_kernel"), 0)
                             if pmc_ratio("kernel_block_sym_kernel") else None),
                 "note": "kernel_block_sym_kernel: 2*N^2*P algorithmic flops per launch (the symmetric variant "
-                        "executes half of them and mirrors); at P=20 the build is HBM-write bound (8 N^2 bytes, "
+                        "executes half of them and mirrors); for P <~ 40 the build is HBM-write bound (8 N^2 bytes, "
                         "AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
             "roofline": roof,
             "other_kernels": [c for c in cands if c is not roof],
         }
         if tu_ms > 0:
             res["trailing_update"] = {"tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3), "launches": tu_n}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(p, args.cpu_n, args.seed)
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

@@ -52,6 +52,9 @@ struct bigkrls_ctx {
   // dynamic-LDS limit was raised, and co-resident workgroup capacities of the persistent kernels
   std::vector<const void*> dyn_smem_done;
   std::vector<std::pair<const void*, int>> resident_cap;
+  // set while a decomposition is retried after the watchdog of a persistent kernel fired: the
+  // panel QR runs one launch per column and the bulge chasing one launch per wavefront
+  bool no_resident = false;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls

@@ -251,6 +251,14 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             Racc = R if Racc is None else R @ Racc
         return W, Racc, True
 
+    def agree_min(values):
+        """Element-wise minimum of a few host scalars over the ranks (control decisions only)."""
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=Kcols.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return [float(v) for v in t.tolist()]
+
     import time as _t
     _prof = {} if os.environ.get("BIGKRLS_VERBOSE") else None
 
@@ -262,7 +270,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     rng = np.random.default_rng(seed)
     W0 = backend.from_numpy(rng.random((n, b)) - 0.5)
     Bj, _, ok = cholqr2(W0)
-    if not ok:
+    if not agree_min([1.0 if ok else 0.0])[0] > 0.5:
         raise RuntimeError("eigen_krylov_dist: start block is rank deficient")
     Ball = torch.empty((maxdim, n), dtype=torch.float64, device=Bj.device)
     Ball[:b] = Bj
@@ -287,6 +295,10 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         _tick("cholqr2", _t0); _t0 = _t.perf_counter()
         Ablk.append(0.5 * (Aj + Aj.T))
         steps += 1
+        # Every branch below is taken on values agreed by all ranks (a last-bit difference between
+        # replicas must never let one rank leave the loop while the others enter the next
+        # all-gather): the breakdown flag is the minimum over the ranks.
+        ok = bool(agree_min([1.0 if ok else 0.0])[0] > 0.5)
         last = (not ok) or steps >= maxsteps
         if ok:
             Bblk.append(R)
@@ -303,13 +315,16 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             if ok:
                 Ylast = _host(backend, Y[:, m - b:]).T                     # b x neig
                 worst = float(np.max(np.linalg.norm(Bblk[-1] @ Ylast, axis=0)))
-            if worst <= tol * abs(theta[0]) or last:
-                converged = worst <= tol * abs(theta[0])
+            # agreed values: the largest residual and the smallest theta_1 over the ranks
+            neg_worst, theta1 = agree_min([-worst, abs(float(theta[0]))])
+            worst = -neg_worst
+            if worst <= tol * theta1 or last:
+                converged = worst <= tol * theta1
                 break
             inc = max(2, steps // 6)                                 # same schedule as csrc/eigen.hip
             if prev_worst > 0.0 and 0.0 < worst < prev_worst:
                 rate = math.log(worst / prev_worst) / (steps - prev_steps)
-                need = math.log(tol * abs(theta[0]) / worst) / rate
+                need = math.log(tol * theta1 / worst) / rate
                 if math.isfinite(need) and need > 0.0:
                     inc = max(1, min(int(math.ceil(need)) + 1, 4 * inc))
             prev_worst, prev_steps = worst, steps

@@ -114,13 +114,25 @@ class _SolveState:
 
 
 def _state(eig: Eigenobject, y: DeviceMatrix) -> _SolveState:
+    """The cached a = Q'y is reused only for the very same tensor object in the very same state:
+    the state keeps a reference to y's tensor (so its address cannot be recycled for another
+    array while the cache lives) and torch's in-place version counter (bumped by every torch
+    write). Writes torch cannot see (a raw kernel through the C ABI) must go through a new
+    DeviceMatrix or `forget_solve_state`."""
     key = "_solve_state"
     st = getattr(eig, key, None)
-    if st is None or getattr(st, "y_ptr", None) != y.t.data_ptr():
+    if st is None or st.y_tensor is not y.t or st.y_version != y.t._version:
         st = _SolveState(eig, y)
-        st.y_ptr = y.t.data_ptr()
+        st.y_tensor = y.t
+        st.y_version = y.t._version
         setattr(eig, key, st)
     return st
+
+
+def forget_solve_state(eig: Eigenobject) -> None:
+    """Drop the cached Q'y of an Eigenobject (after y was overwritten behind torch's back)."""
+    if hasattr(eig, "_solve_state"):
+        delattr(eig, "_solve_state")
 
 
 def bSolveForc(y: DeviceMatrix, Eigenobject: Eigenobject, lambda_: float):

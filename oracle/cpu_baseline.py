@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""CPU baseline of one bigKRLS() fit at the bench workload, timed on the host cores.
+
+TEST / MEASUREMENT INFRASTRUCTURE ONLY (bench.py's `cpu_baseline` leg runs this file as a child
+process; nothing under bigkrls_amd/ imports it).
+
+What is timed ("CPU baseline timed beside it"): the oracle's literal
+restatement of the reference -- same loop structure as src/*.cpp, LAPACK dsyevd and BLAS through
+scipy's OpenBLAS, hand loops single-threaded like the reference -- at the bench size N, phase by
+phase:
+  kernel       src/gauss_kernel.cpp:13-30 row loop, in full
+  eigen        src/eigen.cpp:24 eig_sym == dsyevd of the N x N kernel, in full
+  lambda       src/solveforc.cpp:36-53 row loop: ONE literal probe timed, times the number of probes
+               of the golden-section search (R/bigKRLS_Rcpp_functions.R:38-77)           [extrapolated]
+  coeffs       one more literal solveforc + K %*% c
+  vcov_c       V = (Q diag) Q' (R/bigKRLS.R:299-301), in full
+  vcov_fitted  crossprod(K, V %*% K) (R/bigKRLS.R:307, 4 N^3): a column block of N/frac columns
+               through both products, times frac                                        [extrapolated]
+  derivatives  src/bigderiv_v3.cpp:90-106 for ONE column: L = (x_r - x_i) o K and L c in full,
+               sum(L' V L) on a column block of N/frac columns times frac, then times P  [extrapolated]
+and the efficient port (the O(N^2 K) identities the HIP path uses, oracle `*_fast`) in full at the same N,
+sharing the kernel and eigen measurements. The full literal fit at N=2000 is kept as a second sample.
+
+Protocol: the parent starts this process before it touches the GPU; the process imports numpy/scipy,
+then blocks on stdin until the parent writes a line (the GPU timing is over), so that the two never
+share the host cores. Every finished phase is printed as one JSON line and flushed, so that a
+parent that gives up at its deadline keeps what was measured until then.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--p", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=103)
+    ap.add_argument("--eigtrunc", type=float, default=None)
+    ap.add_argument("--small-n", type=int, default=2000)
+    ap.add_argument("--frac", type=int, default=20, help="the N^3 products run on N/frac columns")
+    ap.add_argument("--no-wait", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import scipy.linalg as sla
+    from oracle import krls_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    # spin the BLAS/LAPACK thread pool up before anything is timed (the first call pays for it)
+    _w = np.random.default_rng(0).standard_normal((256, 256))
+    sla.eigh(_w @ _w.T, driver="evd")
+    emit(phase="ready", cores=int(threads), cpu_count=os.cpu_count())
+    if not args.no_wait:
+        sys.stdin.readline()                       # the parent's "go"
+
+    n, p = args.n, args.p
+    # ---- second sample: the complete literal fit at small N ------------------------------------
+    if args.small_n > 0:
+        Xs_, ys_ = orc.synth(args.small_n, p, args.seed)
+        T = {}
+        t0 = time.perf_counter()
+        orc.fit(ys_, Xs_, literal=True, timings=T, return_squares=False)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.fit(ys_, Xs_, literal=False, return_squares=False)
+        emit(phase="small", n=args.small_n, literal_s=round(dt, 3), efficient_s=round(time.perf_counter() - t0, 3),
+             phases_s={k: round(v, 3) for k, v in T.items()})
+
+    X, y = orc.synth(n, p, args.seed)
+    eigtrunc = args.eigtrunc if args.eigtrunc is not None else (0.001 if n > 3000 else 0.0)
+    sigma = float(p)
+    Xs, ys, _, _, _, _ = orc.standardize(X, y)
+
+    t0 = time.perf_counter()
+    K = orc.gauss_kernel_literal(Xs, sigma)
+    t_kernel = time.perf_counter() - t0
+    emit(phase="kernel", s=round(t_kernel, 3), extrapolated=False)
+
+    t0 = time.perf_counter()
+    vals, vecs = sla.eigh(K, driver="evd")          # eig_sym (dsyevd), src/eigen.cpp:24
+    vals, vecs = vals[::-1].copy(), vecs[:, ::-1]
+    keep = np.nonzero(vals >= eigtrunc * vals[0])[0]
+    k = int(keep.max()) + 1
+    Q = np.ascontiguousarray(-1.0 * vecs[:, :k])    # R/bigKRLS_Rcpp_functions.R:186,192-197
+    del vecs
+    t_eigen = time.perf_counter() - t0
+    eig = orc.EigenObject(values=vals, lastkeeper=k, vectors=Q)
+    emit(phase="eigen", s=round(t_eigen, 3), lastkeeper=k, extrapolated=False)
+
+    # ---- efficient port: lambda search, c (its probes are the literal search's probes too) -----
+    tr = orc.LambdaTrace(0, 0)
+    t0 = time.perf_counter()
+    lam = orc.lambda_search(eig, ys, solver=orc.solveforc_fast, trace=tr)
+    t_lambda_fast = time.perf_counter() - t0
+    nprobes = len(tr.probes)
+    t0 = time.perf_counter()
+    le, c = orc.solveforc_fast(Q, vals, ys, lam)
+    yfit = K @ c
+    t_coeffs_fast = time.perf_counter() - t0
+    emit(phase="efficient_lambda_coeffs", lambda_s=round(t_lambda_fast, 3), coeffs_s=round(t_coeffs_fast, 3),
+         probes=nprobes, lam=lam)
+
+    # ---- literal lambda search: one probe of the row loop, times the number of probes -----------
+    t0 = time.perf_counter()
+    le_l, c_l = orc.solveforc_literal(Q, vals, ys, lam)
+    t_probe = time.perf_counter() - t0
+    assert abs(le_l - le) <= 1e-8 * abs(le)
+    emit(phase="lambda", s=round(t_probe * nprobes, 3), one_probe_s=round(t_probe, 3), probes=nprobes,
+         extrapolated=True)
+    t0 = time.perf_counter()
+    _ = K @ c_l
+    t_coeffs = t_probe + (time.perf_counter() - t0)
+    emit(phase="coeffs", s=round(t_coeffs, 3), extrapolated=False)
+
+    # ---- variance matrices ------------------------------------------------------------------------
+    resid = ys - yfit
+    sigmasq = float(resid @ resid) / n
+    wv = sigmasq * (vals[:k] + lam) ** -2.0
+    t0 = time.perf_counter()
+    V = orc.tcrossprod(orc.multdiag(Q, sigmasq * (vals + lam) ** -2.0), Q)
+    t_vc = time.perf_counter() - t0
+    emit(phase="vcov_c", s=round(t_vc, 3), extrapolated=False)
+    nc = max(1, n // args.frac)
+    scale = n / nc
+    t0 = time.perf_counter()
+    VK = V @ K[:, :nc]
+    _ = K.T @ VK                                    # crossprod(K, V %*% K), R/bigKRLS.R:307
+    t_vf = (time.perf_counter() - t0) * scale
+    del VK, _
+    emit(phase="vcov_fitted", s=round(t_vf, 3), columns=nc, extrapolated=True)
+    t0 = time.perf_counter()
+    dd = vals[:k]
+    Vyhat = (Q * (wv * dd * dd)) @ Q.T
+    t_vf_fast = time.perf_counter() - t0
+    del Vyhat
+
+    # ---- one derivative column, literal (src/bigderiv_v3.cpp:90-106) ------------------------------
+    xj = Xs[:, 0]
+    t0 = time.perf_counter()
+    Lm = (xj[:, None] - xj[None, :]) * K            # :95, :102
+    dcol = (-2.0 / sigma) * (Lm @ c)                # :103
+    t_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    VL = V @ Lm[:, :nc]
+    _ = float(np.sum(Lm.T @ VL))                    # :105 on a column block
+    t_cube = (time.perf_counter() - t0) * scale
+    del VL, Lm
+    t_dcol = t_full + t_cube
+    emit(phase="derivatives", s=round(t_dcol * p, 3), one_column_s=round(t_dcol, 3), columns=nc, extrapolated=True)
+    t0 = time.perf_counter()
+    D, var = orc.derivmat_fast(Xs, K, c, sigma, Q, wv)
+    t_deriv_fast = time.perf_counter() - t0
+    assert np.max(np.abs(D[:, 0] - dcol)) <= 1e-9 * np.max(np.abs(dcol))
+
+    literal = t_kernel + t_eigen + t_probe * nprobes + t_coeffs + t_vc + t_vf + t_dcol * p
+    efficient = t_kernel + t_eigen + t_lambda_fast + t_coeffs_fast + t_vc + t_vf_fast + t_deriv_fast
+    emit(phase="done", n=n, p=p, cores=int(threads), literal_s=round(literal, 2), efficient_s=round(efficient, 2),
+         lastkeeper=k, lam=lam, probes=nprobes,
+         efficient_phases_s={"kernel": round(t_kernel, 3), "eigen": round(t_eigen, 3), "lambda": round(t_lambda_fast, 3),
+                             "coeffs": round(t_coeffs_fast, 3), "vcov_c": round(t_vc, 3),
+                             "vcov_fitted": round(t_vf_fast, 3), "derivatives": round(t_deriv_fast, 3)})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,346 @@
+"""Every BASELINE.json configuration as a full fit on one MI355X.
+
+C2 (N=5000, P=10)   bigKRLS() against the CPU oracle at 1e-6, eigtrunc 0.001 and 0 (quirk Q7 guarded)
+C3 (N=20000, P=20)  eigen residual / orthonormality on the kept vectors at the bench size, and the
+                    top of the spectrum, lambda and c against ARPACK on the host (the oracle's
+                    stand-in for eigs_sym)
+C4 (N=50000, P=20, Neig=512)            size-independent properties + block Lanczos vs the dense path
+C5 (N=100000, P=50, Neig=1024, which.derivatives=c(1,3,5))   the same, plus quirk Q6
+n = 33000           the dense path where bc_wavefront / pq_step are selected by size, not by a switch
+
+Tolerances: 1e-6 relative on c, yhat, lambda, derivatives (north_star); eigen residuals 1e-11.
+The properties are the ones SURVEY.md section 8(d) lists for sizes no CPU oracle reaches: the
+lastkeeper rule, ||K Q - Q D||, ||Q'Q - I||, the normal equations on the kept subspace, the
+derivative identities, trace identities of the variance matrices.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import krls_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def standardized(X, y):
+    return (X - X.mean(0)) / X.std(0, ddof=1), (y - y.mean()) / y.std(ddof=1)
+
+
+def eigen_quality(ops, K, Q, lam):
+    """max |K Q - Q diag(lam)| / lam_1 and max |Q'Q - I| with the products on the device."""
+    k = Q.ncol
+    R = ops.gemm(False, False, K, Q).to_numpy() - Q.to_numpy() * lam[:k]
+    G = ops.gemm(True, False, Q, Q).to_numpy()
+    return float(np.abs(R).max() / lam[0]), float(np.abs(G - np.eye(k)).max())
+
+
+def kept_subspace_checks(ctx, ops, out, K, Q, ys, n):
+    """Identities every fit must satisfy whatever its size, with K and Q on the device:
+    lastkeeper rule (R/bigKRLS_Rcpp_functions.R:190), c and yhat inside span(Q), the normal
+    equations projected on the kept subspace, Neffective (all Neig values, quirk Q5), sigmasq."""
+    d = out["K.eigenvalues"]
+    k = out["lastkeeper"]
+    lam = out["lambda"]
+    c = out["coeffs"]
+    yhat = out["yfitted.std"]
+    assert np.all(np.diff(d) <= 1e-9 * d[0])
+    assert abs(out["Neffective"] - (n - np.sum(d / (d + lam)))) < 1e-9 * n
+    cd, yd = ctx.from_numpy(c), ctx.from_numpy(ys)
+    a_c = ops.matvec(Q, cd, trans=True).to_numpy().ravel()              # Q'c
+    a_y = ops.matvec(Q, yd, trans=True).to_numpy().ravel()              # Q'y
+    # c = Q (Q'y / (d + lam))  <=>  Q'c = Q'y/(d+lam) and c in span(Q)
+    assert rel(a_c, a_y / (d[:k] + lam)) < 1e-8
+    c_proj = ops.matvec(Q, ctx.from_numpy(a_c)).to_numpy().ravel()
+    assert rel(c_proj, c) < 1e-9
+    # yhat = K c (full K, R/bigKRLS.R:291) and, on the kept pairs, = Q (d Q'y/(d+lam))
+    Kc = ops.matvec(K, cd).to_numpy().ravel()
+    assert rel(Kc, yhat) < 1e-10
+    yk = ops.matvec(Q, ctx.from_numpy(d[:k] * a_y / (d[:k] + lam))).to_numpy().ravel()
+    assert rel(yk, yhat) < 1e-8
+    # (K + lam I) c = y on the kept subspace
+    r = Kc + lam * c - ys
+    assert np.abs(ops.matvec(Q, ctx.from_numpy(r), trans=True).to_numpy()).max() < 1e-9 * np.abs(a_y).max()
+    assert abs(out["sigmasq"] - np.sum((ys - yhat) ** 2) / n) < 1e-12
+    g = ops.bSolveForc(yd, ops.Eigenobject(values=d, lastkeeper=k, vectors=Q, values_dev=ctx.from_numpy(d)), lam)
+    assert abs(g["Le"] - out["Le"]) <= 1e-12 * out["Le"]
+
+
+def derivative_identities(ctx, ops, out, K, Xs, cols, sigma):
+    """Continuous columns: D_j = (-2/sigma) (x_j o Kc - K (x_j o c)) (src/bigderiv_v3.cpp:90-103 in its
+    O(N^2) form) recomputed with plain matvecs, independent of the fused derivative kernel."""
+    c = out["coeffs"]
+    Kc = out["yfitted.std"]
+    D = out["derivatives.std"]
+    for i, j in enumerate(cols):
+        x = Xs[:, j]
+        Kxc = ops.matvec(K, ctx.from_numpy(x * c)).to_numpy().ravel()
+        assert rel(D[:, i], (-2.0 / sigma) * (x * Kc - Kxc)) < 1e-9, j
+
+
+# --------------------------------------------------------------------------------------------
+# C2
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("eigtrunc", [0.001, 0.0])
+def test_c2_full_fit_vs_oracle(ctx, eigtrunc):
+    """BASELINE.json configs[1]: N=5000, P=10, seed 102, full eigendecomposition, all derivatives,
+    vcov matrices; eigtrunc = 0.001 (the default for n > 3000) and 0 (quirk Q7 --
+    c-parity at eigtrunc=0 is only well posed when min(d) > 1e-9 max(d), asserted first)."""
+    import bigkrls_amd as bk
+    n, p = 5000, 10
+    X, y = orc.synth(n, p, 102)
+    trace_ref = orc.LambdaTrace(0, 0)
+    ref = orc.fit(y, X, eigtrunc=eigtrunc, literal=False, trace=trace_ref)
+    d = ref["K.eigenvalues"]
+    if eigtrunc == 0.0:
+        assert d.min() > 1e-9 * d.max(), "Q7: K numerically singular, c-parity ill-posed at eigtrunc=0"
+        assert ref["lastkeeper"] == n
+    tr = []
+    out = bk.bigKRLS(y, X, eigtrunc=eigtrunc, ctx=ctx, trace=tr)
+    assert out["lastkeeper"] == ref["lastkeeper"]
+    assert rel(out["K.eigenvalues"], d) < 1e-11
+    assert len(tr) == len(trace_ref.probes)                      # same golden-section path (Q8)
+    assert abs(out["lambda"] - ref["lambda"]) <= TOL * ref["lambda"]
+    for key in ["coeffs", "yfitted", "derivatives", "avgderivatives", "var.avgderivatives",
+                "derivatives.std", "var.avgderivatives.std"]:
+        assert rel(out[key], ref[key]) < TOL, key
+    for key in ["R2", "R2AME", "Looe", "Neffective", "sigmasq"]:
+        assert abs(out[key] - ref[key]) <= TOL * abs(ref[key]), key
+    for key in ["K", "vcov.est.c", "vcov.est.fitted"]:           # n > 2500: device-resident outputs
+        assert hasattr(out[key], "to_numpy")
+        assert rel(out[key].to_numpy(), ref[key]) < TOL, key
+
+
+# --------------------------------------------------------------------------------------------
+# C3
+# --------------------------------------------------------------------------------------------
+def test_c3_eigen_residuals_and_host_arpack(ctx):
+    """BASELINE.json configs[2] (the bench workload), N=20000, P=20, eigtrunc=0.001: the only size at
+    which pq_resident runs 79 workgroups with the two-level exchange and bc_resident 312 co-resident
+    workgroups. (i) residual and orthonormality of the kept eigenvectors; (ii) the top of the spectrum
+    against ARPACK on the host (what the reference's eigs_sym is; scipy's build), then lambda and c
+    recomputed on the host from those pairs with the oracle's lambda search."""
+    import scipy.sparse.linalg as ssl
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    n, p = 20000, 20
+    X, y = orc.synth(n, p, 103)
+    Xs, ys = standardized(X, y)
+    out = bk.bigKRLS(y, X, ctx=ctx)
+    k = out["lastkeeper"]
+    d = out["K.eigenvalues"]
+    assert k == int(np.max(np.nonzero(d >= 0.001 * d[0])[0])) + 1
+    assert abs(d.sum() - n) < 1e-10 * n
+    K = out["K"]
+    eo = ops.bEigen(K, n, 0.001)
+    assert eo.lastkeeper == k and np.array_equal(eo.values, d)   # deterministic: identical to the fit's
+    res, orth = eigen_quality(ops, K, eo.vectors, d)
+    print(f"C3: kept {k}, max|KQ-QD|/d1 = {res:.2e}, max|Q'Q-I| = {orth:.2e}")
+    assert res < 1e-11 and orth < 1e-11
+    kept_subspace_checks(ctx, ops, out, K, eo.vectors, ys, n)
+    derivative_identities(ctx, ops, out, K, Xs, [0, 7, 19], float(p))
+    # ---- host oracle for the top of the spectrum ------------------------------------------------
+    t0 = time.perf_counter()
+    Kh = K.to_numpy()
+    assert rel(Kh[:, 17], orc.temp_kernel_literal(Xs, Xs[17:18], float(p)).ravel()) < 1e-13
+    kk = k + 6
+    hv, hq = ssl.eigsh(Kh, k=kk, which="LA", tol=1e-13, ncv=min(n - 1, 2 * kk + 40))
+    order = np.argsort(hv)[::-1]
+    hv, hq = hv[order], hq[:, order]
+    print(f"C3: host ARPACK top-{kk} in {time.perf_counter() - t0:.1f} s")
+    assert rel(d[:kk], hv) < 1e-11
+    # lambda search and coefficients on the host from ARPACK's pairs; the bounds need all N
+    # eigenvalues (quirk Q5), which only the device has: the device's tail is checked by the trace
+    # identity above and enters only through sum(d/(d+L)) in the bounds loops
+    eig_h = orc.EigenObject(values=np.concatenate([hv[:k], d[k:]]), lastkeeper=k, vectors=hq[:, :k])
+    lam_h = orc.lambda_search(eig_h, ys)
+    assert abs(out["lambda"] - lam_h) <= TOL * lam_h
+    le_h, c_h = orc.solveforc_fast(eig_h.vectors, eig_h.values, ys, lam_h)
+    assert rel(out["coeffs"], c_h) < TOL
+    assert abs(out["Le"] - le_h) <= TOL * le_h
+    assert rel(out["yfitted.std"], Kh @ c_h) < TOL
+    del Kh
+
+
+# --------------------------------------------------------------------------------------------
+# n > 32768 through the dense path
+# --------------------------------------------------------------------------------------------
+def test_dense_path_above_resident_limit(ctx, monkeypatch):
+    """n = 33000 > 32768: more band locations than co-resident workgroups, so the library itself selects
+    bc_wavefront (2n launches) and, for the first panels (> 80 workgroups), pq_step -- no environment
+    switch. Kept eigenpairs at eigtrunc 0.001: residual, orthonormality, trace."""
+    from bigkrls_amd import ops
+    from bigkrls_amd.synth import synth
+    for v in ("BIGKRLS_BC", "BIGKRLS_PQ", "BIGKRLS_EIG"):
+        monkeypatch.delenv(v, raising=False)
+    n, p = 33000, 8
+    X, _ = synth(n, p, 77)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    t0 = time.perf_counter()
+    eo = ops.bEigen(K, None, 0.001)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    k = eo.lastkeeper
+    assert 0 < k < n and k == int(np.max(np.nonzero(eo.values >= 0.001 * eo.values[0])[0])) + 1
+    res, orth = eigen_quality(ops, K, eo.vectors, eo.values)
+    tr = abs(eo.values.sum() - n) / n
+    print(f"n=33000 dense: {dt:.2f} s, kept {k}, resid {res:.2e}, orth {orth:.2e}, trace {tr:.2e}")
+    assert res < 1e-11 and orth < 1e-11 and tr < 1e-11
+    del K, eo
+    ctx.release_workspace()
+
+
+# --------------------------------------------------------------------------------------------
+# C4
+# --------------------------------------------------------------------------------------------
+def test_c4_fit_properties_and_lanczos_vs_dense(ctx, monkeypatch):
+    """BASELINE.json configs[3] on one GPU: N=50000, P=20, Neig=512 (the reference's eigs_sym branch,
+    src/eigen.cpp:18-22 -> block Lanczos here)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    from bigkrls_amd.synth import synth
+    monkeypatch.delenv("BIGKRLS_EIGK", raising=False)
+    n, p, neig = 50000, 20, 512
+    X, y = synth(n, p, 104)
+    Xs, ys = standardized(X, y)
+    T = {}
+    out = bk.bigKRLS(y, X, Neig=neig, ctx=ctx, timings=T)
+    print("C4 timings:", {k: round(v, 3) for k, v in T.items()}, "lastkeeper", out["lastkeeper"])
+    d = out["K.eigenvalues"]
+    k = out["lastkeeper"]
+    assert d.shape == (neig,)
+    assert k == int(np.max(np.nonzero(d >= 0.001 * d[0])[0])) + 1     # lastkeeper rule, eigtrunc default 0.001
+    K = out["K"]
+    eo = ops.bEigen(K, neig, 0.001)
+    assert eo.lastkeeper == k and rel(eo.values, d) < 1e-13
+    res, orth = eigen_quality(ops, K, eo.vectors, d)
+    print(f"C4: kept {k}, resid {res:.2e}, orth {orth:.2e}")
+    assert res < 1e-9 and orth < 1e-11        # Lanczos stops at Ritz residuals of 1e-10 theta_1
+    kept_subspace_checks(ctx, ops, out, K, eo.vectors, ys, n)
+    derivative_identities(ctx, ops, out, K, Xs, [0, 11], float(p))
+    assert np.isfinite(out["derivatives"]).all() and np.all(out["var.avgderivatives"] > 0)
+    sd2 = y.std(ddof=1) ** 2
+    lam = out["lambda"]
+    tv = out["vcov.est.c"].diag().sum() / sd2
+    tf = out["vcov.est.fitted"].diag().sum() / sd2
+    assert abs(tv - out["sigmasq"] * np.sum((d[:k] + lam) ** -2.0)) < 1e-8 * tv
+    assert abs(tf - out["sigmasq"] * np.sum(d[:k] ** 2 * (d[:k] + lam) ** -2.0)) < 1e-8 * tf
+    Qk = eo.vectors
+    vk = d.copy()
+    del out
+    # ---- the same top-512 pairs through the dense two-stage path ------------------------------------
+    monkeypatch.setenv("BIGKRLS_EIGK", "dense")
+    t0 = time.perf_counter()
+    de = ops.bEigen(K, neig, 0.001)
+    ctx.sync()
+    print(f"C4 dense path: {time.perf_counter() - t0:.2f} s")
+    assert de.lastkeeper == k
+    assert rel(de.values, vk) < 1e-11
+    rng = np.random.default_rng(1)
+    z = ctx.from_numpy(rng.standard_normal(n))
+    pk = ops.matvec(Qk, ops.matvec(Qk, z, trans=True)).to_numpy()
+    pd = ops.matvec(de.vectors, ops.matvec(de.vectors, z, trans=True)).to_numpy()
+    gap = (vk[k - 1] - (vk[k] if k < neig else 0.0)) / vk[0]
+    assert rel(pk, pd) < max(1e-7, 1e-11 / max(gap, 1e-300))          # same invariant subspace
+    del de, Qk, K, eo
+    ctx.release_workspace()
+
+
+# --------------------------------------------------------------------------------------------
+# C5
+# --------------------------------------------------------------------------------------------
+def test_c5_fit_properties_which_derivatives(ctx, monkeypatch):
+    """BASELINE.json configs[4] on one GPU: N=100000, P=50, Neig=1024, which.derivatives=c(1,3,5).
+    K, vcov.est.c and vcov.est.fitted are 80 GB each; standardised derivatives are checked against the
+    matvec identity, the rescaled ones against quirk Q6 (R/bigKRLS.R:395-397 divides column i of the
+    subset by X.init.sd[i], not by the sd of the selected column)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    from bigkrls_amd.synth import synth
+    monkeypatch.delenv("BIGKRLS_EIGK", raising=False)
+    n, p, neig = 100000, 50, 1024
+    which = [1, 3, 5]
+    X, y = synth(n, p, 105)
+    Xs, ys = standardized(X, y)
+    T = {}
+    out = bk.bigKRLS(y, X, Neig=neig, which_derivatives=which, ctx=ctx, timings=T)
+    print("C5 timings:", {k: round(v, 3) for k, v in T.items()}, "lastkeeper", out["lastkeeper"])
+    d = out["K.eigenvalues"]
+    k = out["lastkeeper"]
+    assert d.shape == (neig,) and k == int(np.max(np.nonzero(d >= 0.001 * d[0])[0])) + 1
+    sd2 = y.std(ddof=1) ** 2
+    lam = out["lambda"]
+    tv = out["vcov.est.c"].diag().sum() / sd2
+    tf = out["vcov.est.fitted"].diag().sum() / sd2
+    assert abs(tv - out["sigmasq"] * np.sum((d[:k] + lam) ** -2.0)) < 1e-8 * tv
+    assert abs(tf - out["sigmasq"] * np.sum(d[:k] ** 2 * (d[:k] + lam) ** -2.0)) < 1e-8 * tf
+    out["vcov.est.c"] = out["vcov.est.fitted"] = None           # 160 GB back to the allocator
+    ctx.torch.cuda.empty_cache()
+    K = out["K"]
+    eo = ops.bEigen(K, neig, 0.001)
+    assert eo.lastkeeper == k and rel(eo.values, d) < 1e-13
+    res, orth = eigen_quality(ops, K, eo.vectors, d)
+    print(f"C5: kept {k}, resid {res:.2e}, orth {orth:.2e}")
+    assert res < 1e-9 and orth < 1e-11
+    kept_subspace_checks(ctx, ops, out, K, eo.vectors, ys, n)
+    cols = [w - 1 for w in which]
+    assert out["derivatives"].shape == (n, 3) and out["derivatives.std"].shape == (n, 3)
+    derivative_identities(ctx, ops, out, K, Xs, cols, float(p))
+    # var(avg derivative), standardised: 4/(sigma^2 n^2) s'Vs with s = x o K1 - K x, V = Q diag(wv) Q'
+    wv = out["sigmasq"] * (d[:k] + lam) ** -2.0
+    K1 = ops.matvec(K, ctx.from_numpy(np.ones(n))).to_numpy().ravel()
+    for i, j in enumerate(cols):
+        x = Xs[:, j]
+        s = x * K1 - ops.matvec(K, ctx.from_numpy(x)).to_numpy().ravel()
+        qs = ops.matvec(eo.vectors, ctx.from_numpy(s), trans=True).to_numpy().ravel()
+        want = 4.0 / (float(p) ** 2 * float(n) ** 2) * float(np.sum(wv * qs * qs))
+        assert abs(out["var.avgderivatives.std"][i] - want) <= 1e-8 * want
+    # quirk Q6: rescaling by X.init.sd[1..3], not by the selected columns' sds
+    sdx = X.std(0, ddof=1)
+    sdy = y.std(ddof=1)
+    for i in range(3):
+        assert rel(out["derivatives"][:, i], out["derivatives.std"][:, i] * sdy / sdx[i]) < 1e-13
+    assert rel(out["var.avgderivatives"].ravel(), (sdy / sdx[cols]) ** 2 * out["var.avgderivatives.std"]) < 1e-13
+    assert rel(out["avgderivatives"].ravel(), out["derivatives"].mean(0)) < 1e-13
+    del out, K, eo
+    ctx.release_workspace()
+    ctx.torch.cuda.empty_cache()
+
+
+# --------------------------------------------------------------------------------------------
+# in-process recovery paths of the eigensolver
+# --------------------------------------------------------------------------------------------
+def test_eigen_watchdog_retry_and_lanczos_fallback(ctx, monkeypatch):
+    """BIGKRLS_FAULT=watchdog: the first attempt reports a fired persistent-kernel watchdog after
+    stage 1; the call must redo the decomposition with the per-step kernels and succeed.
+    BIGKRLS_FAULT=noconv: the block Lanczos reports non-convergence; the same call must fall through
+    to the dense path (no user-visible switch, like the reference's eigs_sym branch)."""
+    from bigkrls_amd import ops
+    n, p = 3000, 5
+    X, _ = orc.synth(n, p, 9)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    good = ops.bEigen(K, 40, -1.0)
+    monkeypatch.setenv("BIGKRLS_FAULT", "watchdog")
+    again = ops.bEigen(K, 40, -1.0)
+    assert rel(again.values, good.values) < 1e-12
+    res, orth = eigen_quality(ops, K, again.vectors, again.values)
+    assert res < 1e-11 and orth < 1e-11
+    monkeypatch.setenv("BIGKRLS_FAULT", "noconv")
+    n2 = 16384                                                   # the size at which Lanczos is chosen by default
+    X2, _ = orc.synth(n2, p, 10)
+    K2 = ops.bGaussKernel(ctx.from_numpy((X2 - X2.mean(0)) / X2.std(0, ddof=1)), float(p))
+    fb = ops.bEigen(K2, 64, -1.0)
+    monkeypatch.delenv("BIGKRLS_FAULT")
+    kr = ops.bEigen(K2, 64, -1.0)
+    assert rel(fb.values, kr.values) < 1e-10
+    res, orth = eigen_quality(ops, K2, fb.vectors, fb.values)
+    assert res < 1e-11 and orth < 1e-11
