@@ -32,6 +32,29 @@ pf64 = C.POINTER(C.c_double)
 pi64 = C.POINTER(C.c_int64)
 pi32 = C.POINTER(C.c_int32)
 
+class FitOptions(C.Structure):
+    """bigkrls_fit_options (include/bigkrls.h)."""
+    _fields_ = [("struct_bytes", i64), ("sigma", f64), ("lambda_", f64), ("L", f64), ("U", f64),
+                ("eigtrunc", f64), ("neig", i64), ("derivative", i32), ("vcov_est", i32), ("acf", i32),
+                ("reserved", i32), ("which_derivatives", pi64), ("n_which", i64)]
+
+
+class FitOutputs(C.Structure):
+    """bigkrls_fit_outputs (include/bigkrls.h)."""
+    _fields_ = [("struct_bytes", i64),
+                ("eigenvalues", vp), ("coeffs", vp), ("yfitted", vp), ("yfitted_std", vp),
+                ("derivatives", vp), ("derivatives_std", vp), ("avgderivatives", vp),
+                ("var_avgderivatives", vp), ("var_avgderivatives_std", vp), ("binaryindicator", vp),
+                ("lambda_trace", vp), ("max_trace", i64),
+                ("d_K", vp), ("d_vcov_c", vp), ("d_vcov_fitted", vp),
+                ("lastkeeper", i64), ("neig", i64), ("n_deriv", i64), ("n_probes", i64),
+                ("sigma", f64), ("lambda_", f64), ("Le", f64), ("Looe", f64), ("sigmasq", f64),
+                ("R2", f64), ("R2AME", f64), ("Neffective", f64), ("Neffective_acf", f64),
+                ("y_mean", f64), ("y_sd", f64), ("phase_s", f64 * 8)]
+
+
+PHASES = ("h2d", "kernel", "eigen", "lambda", "coeffs", "vcov_c", "vcov_fitted", "derivatives")
+
 # name -> argtypes (every function returns int unless listed in _RESTYPES)
 SIGNATURES = {
     "bigkrls_version": [],
@@ -86,6 +109,9 @@ SIGNATURES = {
     "bigkrls_dev_diag": [vp, vp, i64, i64, vp],
     "bigkrls_dev_scale": [vp, i64, f64, vp],
     "bigkrls_dev_neffective": [vp, vp, i64, i64, i64, vp],
+    # level 2, whole path
+    "bigkrls_fit": [vp, vp, vp, i64, i64, C.POINTER(FitOptions), C.POINTER(FitOutputs)],
+    "bigkrls_predict": [vp, vp, i64, i64, vp, vp, f64, vp, i64, vp, f64, vp, vp, vp, vp],
 }
 _RESTYPES = {
     "bigkrls_last_error": C.c_char_p,

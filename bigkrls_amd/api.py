@@ -14,7 +14,9 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from . import ops
+import ctypes as C
+
+from . import _lib, ops
 from .device import Context, DeviceMatrix, is_device_matrix
 
 _default_ctx: Optional[Context] = None
@@ -61,6 +63,17 @@ def _as_host_matrix(X) -> np.ndarray:
     return X
 
 
+def _call_native(name, *args):
+    """A library call whose BIGKRLS_EINVAL (the reference's validation errors, with R's message
+    text) becomes the ValueError the R-mirroring API raises; everything else stays a BigKRLSError."""
+    try:
+        _lib.call(name, *args)
+    except _lib.BigKRLSError as e:
+        if e.code == _lib.EINVAL:
+            raise ValueError(str(e).split(": ", 2)[-1]) from None
+        raise
+
+
 def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None, vcov_est=True,
             Neig=None, eigtrunc=None, lambda_=None, L=None, U=None, tol=None,
             acf=False, noisy=None, ctx: Optional[Context] = None,
@@ -68,181 +81,143 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
             trace: Optional[list] = None) -> BigKRLS:
     """Kernel-regularised least squares fit (R/bigKRLS.R:97-516).
 
-    `which_derivatives` is 1-based like R.  `lambda_` is R's `lambda`.
-    Persistence arguments (model_subfolder_name, ...) and Ncores/acf are out of
-    scope.  `timings` (optional dict) receives per-phase
-    wall-clock seconds measured with HIP events on the context's stream.
+    The numeric body -- validation of the data, standardisation, the five steps and the rescaling
+    (R/bigKRLS.R:175-470) -- is ONE call into the C ABI, `bigkrls_fit` (include/bigkrls.h,
+    csrc/fit.hip); this function checks the argument types, allocates the outputs (the reference's
+    ownership rule: the caller allocates, native code writes in place) and assembles the list `w`.
+    `which_derivatives` is 1-based like R.  `lambda_` is R's `lambda`.  Persistence arguments
+    (model_subfolder_name, ...) and Ncores are out of scope.  `timings`
+    (optional dict) receives per-phase seconds measured with HIP events on the context's stream;
+    `trace` (optional list) the (lambda, Le) probes of the golden-section search.
     """
     ctx = ctx or default_context()
     if X is None or y is None:
         raise ValueError("y and X are required")
     return_big_rectangles = is_device_matrix(X)                                  # :149
-    # column-major like R: the per-column statistics below and the upload read contiguous columns
+    # column-major like R / the C ABI
     Xh = np.array(_as_host_matrix(X), dtype=np.float64, order="F")
-    yh = np.array(_as_host_matrix(y), dtype=np.float64).ravel()
+    yh = np.ascontiguousarray(np.array(_as_host_matrix(y), dtype=np.float64).ravel())
     n, p = Xh.shape
     return_big_squares = return_big_rectangles or n > 2500                       # :150
     w = BigKRLS()
     w["has.big.matrices"] = bool(return_big_squares or return_big_rectangles)
     noisy = (n > 2000) if noisy is None else bool(noisy)                          # :153
     xlabs = [f"x{i + 1}" for i in range(p)]                                       # :167
-    w["X"] = Xh.copy()
-    X_init_sd = Xh.std(axis=0, ddof=1) if n > 1 else np.zeros(p)                  # :179
-    if np.isnan(Xh).any():                                                        # :183-187
-        bad = [str(j + 1) for j in range(p) if np.isnan(Xh[:, j]).any()]
-        raise ValueError("the following columns in X contain missing data, which must be removed: "
-                         + ", ".join(bad))
-    acf = bool(acf) and p > 2                                                     # :192
-    Neig = min(n, int(Neig)) if Neig is not None else n                           # :194
-    if eigtrunc is None:                                                          # :195-201
-        eigtrunc = 0.001 if n > 3000 else 0.0
-    elif not np.isscalar(eigtrunc) or eigtrunc < 0 or eigtrunc > 1:
+    # ---- argument checks the C ABI cannot see (its "unset" is <= 0 / NULL) ----------------------
+    if eigtrunc is not None and (not np.isscalar(eigtrunc) or eigtrunc < 0 or eigtrunc > 1):   # :195-201
         raise ValueError("eigtrunc must be between 0 (no truncation) and 1 (keep largest only).")
     if which_derivatives is not None:                                             # :206-215
         if not derivative:
             raise ValueError("which.derivative requires derivative = TRUE")
         which_derivatives = [int(i) for i in which_derivatives]
-        if not all(1 <= i <= p for i in which_derivatives):
+        if not which_derivatives or not all(1 <= i <= p for i in which_derivatives):
             raise ValueError("which.derivatives must index columns of X")
-    if X_init_sd.min() == 0:                                                      # :217
-        raise ValueError("The following columns in X are constant and must be removed: "
-                         + ", ".join(str(j + 1) for j in np.nonzero(X_init_sd == 0)[0]))
     if n != yh.shape[0]:
         raise ValueError("nrow(X) not equal to number of elements in y.")
-    if np.isnan(yh).any():
-        raise ValueError("y contains missing data.")
-    if _sd(yh) == 0:
-        raise ValueError("y is a constant.")
     if lambda_ is not None and not (np.isscalar(lambda_) and lambda_ > 0):        # :225
         raise ValueError("lambda must be a positive scalar")
     if sigma is not None and not (np.isscalar(sigma) and sigma > 0):              # :227
         raise ValueError("sigma must be a positive scalar")
-    sigma = float(p) if sigma is None else float(sigma)                           # :230
-    if tol is not None and not (np.isscalar(tol) and tol > 0):                    # :232-236
+    if tol is not None and not (np.isscalar(tol) and tol > 0):                    # :232-236 (validated, never forwarded: :274-275)
         raise ValueError("tol must be a positive scalar")
-    if derivative and not vcov_est:                                               # :239
-        raise ValueError("vcov.est is needed to get derivatives (derivative==TRUE requires vcov.est=TRUE).")
-    x_is_binary = ops.binary_columns(Xh)                                          # :242
+    if U is not None and not (np.isscalar(U) and U > 0):
+        raise ValueError("U must be a positive scalar")
+    if L is not None and not (np.isscalar(L) and L >= 0):
+        raise ValueError("L must be a non-negative scalar")
+    if Neig is not None and int(Neig) < 1:
+        raise ValueError("Neig must be a positive integer")
+    neig = min(n, int(Neig)) if Neig is not None else n                           # :194
+    pd = 0 if not derivative else (p if which_derivatives is None else len(which_derivatives))
 
-    y_init = yh.copy()
-    y_init_sd = _sd(y_init)                                                       # :248
-    y_init_mean = float(y_init.mean())
-    Xs = (Xh - Xh.mean(axis=0)) / X_init_sd                                       # :251-253
-    ys = (yh - yh.mean()) / _sd(yh)                                               # :254
+    opt = _lib.FitOptions()
+    opt.struct_bytes = C.sizeof(_lib.FitOptions)
+    opt.sigma = -1.0 if sigma is None else float(sigma)
+    opt.lambda_ = -1.0 if lambda_ is None else float(lambda_)
+    opt.L = -1.0 if L is None else float(L)
+    opt.U = -1.0 if U is None else float(U)
+    opt.eigtrunc = -1.0 if eigtrunc is None else float(eigtrunc)
+    opt.neig = neig
+    opt.derivative = int(bool(derivative))
+    opt.vcov_est = int(bool(vcov_est))
+    opt.acf = int(bool(acf))
+    which_arr = None
+    if which_derivatives is not None:
+        which_arr = np.ascontiguousarray(which_derivatives, dtype=np.int64)
+        opt.which_derivatives = which_arr.ctypes.data_as(_lib.pi64)
+        opt.n_which = which_arr.size
 
-    T = timings if timings is not None else {}
-    ev = [ctx.event()]
-    names: List[str] = []
+    def hbuf(*shape):
+        return np.empty(shape, dtype=np.float64, order="F")
 
-    def mark(name):
-        names.append(name)
-        ev.append(ctx.event())
+    out = _lib.FitOutputs()
+    out.struct_bytes = C.sizeof(_lib.FitOutputs)
+    vals, coeffs, yf, yfs = hbuf(neig), hbuf(n), hbuf(n), hbuf(n)
+    isbin = np.zeros(p, dtype=np.int32)
+    max_trace = 512
+    tracebuf = hbuf(2 * max_trace)
+    out.eigenvalues, out.coeffs = vals.ctypes.data, coeffs.ctypes.data
+    out.yfitted, out.yfitted_std = yf.ctypes.data, yfs.ctypes.data
+    out.binaryindicator = isbin.ctypes.data
+    out.lambda_trace, out.max_trace = tracebuf.ctypes.data, max_trace
+    if derivative:
+        D, Dstd = hbuf(n, pd), hbuf(n, pd)
+        avg, var, varstd = hbuf(pd), hbuf(pd), hbuf(pd)
+        out.derivatives, out.derivatives_std = D.ctypes.data, Dstd.ctypes.data
+        out.avgderivatives, out.var_avgderivatives = avg.ctypes.data, var.ctypes.data
+        out.var_avgderivatives_std = varstd.ctypes.data
+    K = ctx.empty(n, n)                                                           # :434
+    out.d_K = K.ptr
+    vcovmatc = vcovmatyhat = None
+    if vcov_est:
+        vcovmatc, vcovmatyhat = ctx.empty(n, n), ctx.empty(n, n)
+        out.d_vcov_c, out.d_vcov_fitted = vcovmatc.ptr, vcovmatyhat.ptr
 
     t_wall0 = time.perf_counter()
-    Xd = ctx.from_numpy(Xs)
-    yd = ctx.from_numpy(ys)
-    mark("h2d")
+    _call_native("bigkrls_fit", ctx.handle, Xh.ctypes.data, yh.ctypes.data, n, p, C.byref(opt), C.byref(out))
+    t_native = time.perf_counter() - t_wall0
 
-    K = ops.bGaussKernel(Xd, sigma)                                               # Step 1 (:262)
-    mark("kernel")
-    Eigenobject = ops.bEigen(K, Neig, eigtrunc)                                   # Step 2 (:266)
-    mark("eigen")
-    w["K.eigenvalues"] = Eigenobject.values                                       # :268
-    w["lastkeeper"] = Eigenobject.lastkeeper                                      # :269
-
-    if lambda_ is None:                                                           # Step 3 (:271-278)
-        lambda_ = ops.bLambdaSearch(L=L, U=U, y=yd, Eigenobject=Eigenobject, noisy=False,
-                                    trace=trace)  # NB: `tol` is not forwarded (:274-275)
-    mark("lambda")
-    vals = Eigenobject.values
-    w["Neffective"] = n - float(np.sum(vals / (vals + lambda_)))                  # :280
-
-    out = ops.bSolveForc(y=yd, Eigenobject=Eigenobject, lambda_=lambda_)          # Step 4 (:286)
-    coeffs_d = out["coeffs"]
-    yfitted_d = ops.matvec(K, coeffs_d)                                           # :291
-    coeffs = coeffs_d.to_numpy().ravel()
-    yfitted = yfitted_d.to_numpy().ravel()
-    mark("coeffs")
-
-    vcovmatc = vcovmatyhat = None
-    wv = None
-    sigmasq = None
-    if vcov_est:
-        resid = ys - yfitted
-        sigmasq = float(resid @ resid) / n                                        # :294
-        kk = Eigenobject.lastkeeper
-        wv = sigmasq * (vals[:kk] + lambda_) ** -2.0
-        m = ops.bMultDiag(Eigenobject.vectors, sigmasq * (vals + lambda_) ** -2.0)   # :299
-        vcovmatc = ops.bTCrossProd(m, Eigenobject.vectors)                        # :301
-        mark("vcov_c")
-        # :307  crossprod(K, vcovmatc %*% K) == Q diag(wv d^2) Q' because K Q = Q D on the
-        # kept pairs (4 N^3 flops -> 2 N^2 K)
-        m2 = ops.bMultDiag(Eigenobject.vectors, wv * vals[:kk] ** 2)
-        vcovmatyhat = ops.bTCrossProd(m2, Eigenobject.vectors)
-        del m, m2
-        mark("vcov_fitted")
-
-    if derivative:                                                                # Step 5 (:321-376)
-        cols = list(range(p)) if which_derivatives is None else [i - 1 for i in which_derivatives]
-        X_estimate_h = Xs[:, cols]                                                # :326
-        X_estimate = Xd if which_derivatives is None else ctx.from_numpy(X_estimate_h)
-        deriv_out = ops.bDerivatives(X_estimate, sigma, K, coeffs_d, Eigenobject, wv, X_estimate_h)
-        derivmat = deriv_out["derivatives"].to_numpy()
-        varavgderivmat = np.asarray(deriv_out["varavgderiv"], dtype=np.float64)
-        mark("derivatives")
-        w["derivatives.std"] = derivmat.copy()
-        w["var.avgderivatives.std"] = varavgderivmat.copy()
-        yhat_ame = X_estimate_h @ derivmat.mean(axis=0)                           # :390
-        w["R2AME"] = _cor(y_init, yhat_ame) ** 2                                  # :392
-        derivmat = y_init_sd * derivmat                                           # :394
-        for i in range(derivmat.shape[1]):
-            derivmat[:, i] = derivmat[:, i] / X_init_sd[i]                        # :395-397 (quirk Q6)
-        avgderiv = derivmat.mean(axis=0)[None, :]                                 # :400
-        varavgderivmat = ((y_init_sd / X_init_sd[cols]) ** 2 * varavgderivmat)[None, :]  # :403-407
-
-    if acf:                                                                       # :412-416
-        w["Neffective.acf"] = ops.bNeffective(Xd)
-    else:
-        w["Neffective.acf"] = None                                                # :431
-
+    if trace is not None:
+        for i in range(min(int(out.n_probes), max_trace)):
+            trace.append((float(tracebuf[2 * i]), float(tracebuf[2 * i + 1])))
+    w["X"] = Xh
+    w["K.eigenvalues"] = vals                                                     # :268
+    w["lastkeeper"] = int(out.lastkeeper)                                         # :269
+    w["Neffective"] = float(out.Neffective)                                       # :280
+    if derivative:
+        w["derivatives.std"] = Dstd
+        w["var.avgderivatives.std"] = varstd
+        w["R2AME"] = float(out.R2AME)                                             # :392
+    w["Neffective.acf"] = float(out.Neffective_acf) if (acf and p > 2) else None  # :412-416, :431
     w["coeffs"] = coeffs                                                          # :420
-    w["y"] = y_init
-    w["sigma"] = sigma
-    w["lambda"] = float(lambda_)
-    w["binaryindicator"] = x_is_binary
+    w["y"] = yh
+    w["sigma"] = float(out.sigma)
+    w["lambda"] = float(out.lambda_)
+    w["binaryindicator"] = isbin.astype(bool)
     w["which.derivatives"] = which_derivatives
     w["xlabs"] = xlabs
-    w["yfitted.std"] = yfitted.copy()
-    yf = yfitted * y_init_sd + y_init_mean                                        # :428
-    w["yfitted"] = yf
-    w["R2"] = 1 - (_var(y_init - yf) / (y_init_sd ** 2))                          # :429
-    w["Looe"] = out["Le"] * y_init_sd                                             # :430
-    w["Le"] = out["Le"]
-    w["sigmasq"] = sigmasq
+    w["yfitted.std"] = yfs
+    w["yfitted"] = yf                                                             # :428
+    w["R2"] = float(out.R2)                                                       # :429
+    w["Looe"] = float(out.Looe)                                                   # :430
+    w["Le"] = float(out.Le)
+    w["sigmasq"] = float(out.sigmasq) if vcov_est else None
     w["K"] = K if return_big_squares else K.to_numpy()                            # :434
     if vcov_est:
-        vcovmatc.scale_(y_init_sd ** 2)                                           # :438
-        vcovmatyhat.scale_(y_init_sd ** 2)                                        # :445
-        if return_big_squares:
-            w["vcov.est.c"] = vcovmatc
-            w["vcov.est.fitted"] = vcovmatyhat
-        else:
-            w["vcov.est.c"] = vcovmatc.to_numpy()
-            w["vcov.est.fitted"] = vcovmatyhat.to_numpy()
+        w["vcov.est.c"] = vcovmatc if return_big_squares else vcovmatc.to_numpy()          # :438
+        w["vcov.est.fitted"] = vcovmatyhat if return_big_squares else vcovmatyhat.to_numpy()   # :445
     else:
         w["vcov.est.c"] = None
         w["vcov.est.fitted"] = None
     w["derivative.call"] = derivative
     if derivative:
-        w["avgderivatives"] = avgderiv
-        w["var.avgderivatives"] = varavgderivmat
-        w["derivatives"] = derivmat
-    mark("finish")
-    ctx.sync()
-    T["wall"] = time.perf_counter() - t_wall0
-    for i, nm in enumerate(names):
-        T[nm] = Context.elapsed_ms(ev[i], ev[i + 1]) / 1e3
-    ctx.release_events(ev)
+        w["avgderivatives"] = avg[None, :]                                        # :400
+        w["var.avgderivatives"] = var[None, :]                                    # :403-407
+        w["derivatives"] = D
+    if timings is not None:
+        for name, sec in zip(_lib.PHASES, out.phase_s):
+            timings[name] = float(sec)
+        timings["native"] = t_native
+        timings["wall"] = time.perf_counter() - t_wall0
     w["_ctx"] = ctx
     return w
 
@@ -364,40 +339,38 @@ def summary(object: BigKRLS, degrees: str = "Neffective", probs=(0.05, 0.25, 0.5
 
 def predict(object: BigKRLS, newdata, se_pred=False, correct_SE=True, ytest=None,
             ctx: Optional[Context] = None) -> BigKRLSPredicted:
-    """predict.bigKRLS (R/bigKRLS.R:547-637)."""
+    """predict.bigKRLS (R/bigKRLS.R:547-637); the numeric body (:590-621) is ONE call into the
+    C ABI, `bigkrls_predict` (include/bigkrls.h, csrc/fit.hip)."""
     if not isinstance(object, BigKRLS):
         raise TypeError("Object not of class 'bigKRLS'")
     if se_pred and object.get("vcov.est.c") is None:
         raise ValueError("recompute bigKRLS object with bigKRLS(,vcov.est=TRUE) to compute standard errors")
     ctx = ctx or object.get("_ctx") or default_context()
-    Xh = np.asarray(object["X"], dtype=np.float64)
+    Xh = np.asfortranarray(np.asarray(object["X"], dtype=np.float64))
     bigmatrix_in = is_device_matrix(newdata) or bool(object["has.big.matrices"])   # :582
     nd_init = _as_host_matrix(newdata)
-    nd = np.array(nd_init, dtype=np.float64)
+    nd = np.array(nd_init, dtype=np.float64, order="F")
     if Xh.shape[1] != nd.shape[1]:
         raise ValueError("ncol(newdata) differs from ncol(X) from fitted bigKRLS object")
-    Xmeans = Xh.mean(axis=0)                                                      # :590
-    Xsd = Xh.std(axis=0, ddof=1)                                                  # :591
-    Xs = (Xh - Xmeans) / Xsd                                                      # :593-594
-    nds = (nd - Xmeans) / Xsd                                                     # :596-597
-    Xd = ctx.from_numpy(Xs)
-    ndd = ctx.from_numpy(nds)
-    newdataK = ops.bTempKernel(ndd, Xd, object["sigma"])                          # :599
-    cd = ctx.from_numpy(np.asarray(object["coeffs"], dtype=np.float64))
-    ypred = ops.matvec(newdataK, cd).to_numpy().ravel()                           # :601
-    yv = np.asarray(object["y"], dtype=np.float64)
-    vcov_est_pred = se = None
+    n, p = Xh.shape
+    u = nd.shape[0]
+    yv = np.ascontiguousarray(np.asarray(object["y"], dtype=np.float64).ravel())
+    coeffs = np.ascontiguousarray(np.asarray(object["coeffs"], dtype=np.float64).ravel())
+    ypred = np.empty(u)
+    newdataK = ctx.empty(u, n)
+    se = vcov_est_pred = Vd = None
+    neff = -1.0
     if se_pred:
         V = object["vcov.est.c"]
         Vd = V if is_device_matrix(V) else ctx.from_numpy(np.asarray(V))
-        vy = _var(yv)
-        # var(y) * tcrossprod(newdataK %*% (vcov.est.c * (1/var(y))), newdataK)   (:608)
-        tmp = ops.gemm(False, False, newdataK, Vd, alpha=1.0 / vy)
-        vcov_est_pred = ops.gemm(False, True, tmp, newdataK, alpha=vy)
-        if correct_SE and object.get("Neffective") is not None:
-            vcov_est_pred.scale_(math.sqrt(Xh.shape[0] / float(object["Neffective"])))   # :610-611
-        se = np.sqrt(vcov_est_pred.diag())                                        # :613
-    ypred = ypred * _sd(yv) + float(yv.mean())                                    # :621
+        vcov_est_pred = ctx.empty(u, u)
+        se = np.empty(u)
+        if correct_SE and object.get("Neffective") is not None:                   # :610-611
+            neff = float(object["Neffective"])
+    _call_native("bigkrls_predict", ctx.handle, Xh.ctypes.data, n, p, yv.ctypes.data, coeffs.ctypes.data,
+                 float(object["sigma"]), nd.ctypes.data, u, Vd.ptr if se_pred else None, neff,
+                 ypred.ctypes.data, se.ctypes.data if se_pred else None, newdataK.ptr,
+                 vcov_est_pred.ptr if se_pred else None)
     if not bigmatrix_in:                                                          # :623-626
         vcov_est_pred = None if vcov_est_pred is None else vcov_est_pred.to_numpy()
         newdataK = newdataK.to_numpy()

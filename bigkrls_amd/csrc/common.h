@@ -58,7 +58,7 @@ struct bigkrls_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
-  static constexpr int kSlots = 32;
+  static constexpr int kSlots = 40;
   void* ws[kSlots] = {nullptr};
   int64_t ws_bytes[kSlots] = {0};
   // pinned host scratch for small scalar read-backs
@@ -107,6 +107,10 @@ enum Slot {
   SLOT_EIG_T2 = 28,        // compact-WY T factors of the stage-2 back-transform tasks
   SLOT_EIG_VBIG = 29,      // merged reflector blocks of the stage-1 back-transform
   SLOT_EIG_TBIG = 30,      // ... and their T factors
+  SLOT_FIT_SMALL = 31,     // bigkrls_fit / bigkrls_predict: X, y, eigenvalues, c, yhat, D, S, ...
+  SLOT_FIT_Q = 32,         // ... eigenvectors (n x Neig)
+  SLOT_FIT_M = 33,         // ... Q diag(w) / K_new V
+  SLOT_FIT_K = 34,         // ... the kernel when the caller does not want it back
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

@@ -1,0 +1,489 @@
+// bigkrls_fit() / bigkrls_predict(): the whole hot path behind one C call each.
+//
+// bigkrls_fit is the numeric body of the reference's bigKRLS() (R/bigKRLS.R:175-470): the
+// validation block (:183-240), standardisation (:248-254), step 1 kernel (:262), step 2 eigen
+// (:266-269), step 3 lambda search (:271-278), step 4 coefficients / fitted values / variance
+// matrices (:280-307), step 5 marginal effects (:321-376) and the rescaling back to the original
+// units (:384-445), with every N x N object resident in HBM. bigkrls_predict is predict.bigKRLS()
+// (R/bigKRLS.R:590-621). The host-side arithmetic (means, sds, rescaling) is O(NP).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace bk {
+namespace {
+
+int fit_check_ctx(bigkrls_ctx* ctx) {
+  if (!ctx) {
+    set_error("null context");
+    return BIGKRLS_EINVAL;
+  }
+  BK_HIP(hipSetDevice(ctx->device));
+  return BIGKRLS_OK;
+}
+
+// mean and R's sd() (n - 1 denominator, biganalytics::colsd, R/bigKRLS.R:179,248) of a column
+void mean_sd(const double* x, int64_t n, double* mean, double* sd) {
+  long double s = 0.0L;
+  for (int64_t i = 0; i < n; ++i) s += x[i];
+  const long double m = s / (long double)n;
+  long double q = 0.0L;
+  for (int64_t i = 0; i < n; ++i) {
+    const long double dlt = (long double)x[i] - m;
+    q += dlt * dlt;
+  }
+  *mean = (double)m;
+  *sd = n > 1 ? (double)std::sqrt((double)(q / (long double)(n - 1))) : 0.0;
+}
+
+// exactly two distinct values (R/bigKRLS.R:242, src/bigderiv_v3.cpp:28-31)
+bool two_valued(const double* x, int64_t n, double* lo_out, double* hi_out) {
+  double lo = x[0], hi = x[0];
+  for (int64_t i = 1; i < n; ++i) {
+    lo = std::min(lo, x[i]);
+    hi = std::max(hi, x[i]);
+  }
+  *lo_out = lo;
+  *hi_out = hi;
+  if (lo == hi) return false;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] != lo && x[i] != hi) return false;
+  return true;
+}
+
+double r_cor(const double* a, const double* b, int64_t n) {
+  long double sa = 0, sb = 0;
+  for (int64_t i = 0; i < n; ++i) { sa += a[i]; sb += b[i]; }
+  const long double ma = sa / n, mb = sb / n;
+  long double ab = 0, aa = 0, bb = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const long double x = a[i] - ma, y = b[i] - mb;
+    ab += x * y; aa += x * x; bb += y * y;
+  }
+  return (double)(ab / std::sqrt((double)(aa * bb)));
+}
+
+struct PhaseTimer {
+  bigkrls_ctx* ctx;
+  hipEvent_t ev[9];
+  int n = 0;
+  bool ok = true;
+  explicit PhaseTimer(bigkrls_ctx* c) : ctx(c) {
+    for (auto& e : ev) e = nullptr;
+  }
+  ~PhaseTimer() {
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  void mark() {   // event n closes phase n - 1
+    if (n >= 9) return;
+    if (hipEventCreate(&ev[n]) != hipSuccess) { ok = false; ev[n] = nullptr; return; }
+    if (hipEventRecord(ev[n], ctx->stream) != hipSuccess) ok = false;
+    ++n;
+  }
+  void collect(double* out8) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+    if (!ok) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i + 1 < n; ++i) {
+      float ms = 0.f;
+      if (ev[i] && ev[i + 1] && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) out8[i] = ms * 1e-3;
+    }
+  }
+};
+
+// host <-> device through the context's pinned staging buffer (no user pages are pinned per call)
+int upload(bigkrls_ctx* ctx, double* dst_dev, const double* src_pinned, int64_t n) {
+  if (n > 0)
+    BK_HIP(hipMemcpyAsync(dst_dev, src_pinned, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return BIGKRLS_OK;
+}
+
+int download(bigkrls_ctx* ctx, double* dst_host, const double* src_dev, int64_t n, double* pinned) {
+  if (n <= 0) return BIGKRLS_OK;
+  BK_HIP(hipMemcpyAsync(pinned, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  std::memcpy(dst_host, pinned, (size_t)n * sizeof(double));
+  return BIGKRLS_OK;
+}
+
+}  // namespace
+}  // namespace bk
+
+using namespace bk;
+
+extern "C" {
+
+int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                const bigkrls_fit_options* opt, bigkrls_fit_outputs* out) {
+  BK_TRY(fit_check_ctx(ctx));
+  BK_REQUIRE(h_X && h_y && opt && out, "fit: null argument");
+  BK_REQUIRE(opt->struct_bytes == (int64_t)sizeof(bigkrls_fit_options), "fit: options struct size mismatch");
+  BK_REQUIRE(out->struct_bytes == (int64_t)sizeof(bigkrls_fit_outputs), "fit: outputs struct size mismatch");
+  BK_REQUIRE(n > 1 && p > 0 && n < (1ll << 30), "fit: bad dimensions");
+  hipStream_t st = ctx->stream;
+  const double NaN = std::numeric_limits<double>::quiet_NaN();
+  auto fail = [](const std::string& msg) { set_error(msg); return BIGKRLS_EINVAL; };
+
+  // ---- validation, in the reference's order (R/bigKRLS.R:183-240) -------------------------------
+  {
+    std::string bad;
+    for (int64_t j = 0; j < p; ++j) {
+      const double* x = h_X + j * n;
+      bool has_nan = false;
+      for (int64_t i = 0; i < n && !has_nan; ++i) has_nan = std::isnan(x[i]);
+      if (has_nan) bad += (bad.empty() ? "" : ", ") + std::to_string(j + 1);
+    }
+    if (!bad.empty())
+      return fail("the following columns in X contain missing data, which must be removed: " + bad);   // :183-187
+  }
+  const bool acf = opt->acf != 0 && p > 2;                                                             // :192
+  const int64_t neig = (opt->neig > 0) ? std::min<int64_t>(n, opt->neig) : n;                          // :194
+  double eigtrunc = opt->eigtrunc;
+  if (eigtrunc < 0.0 || std::isnan(eigtrunc)) eigtrunc = n > 3000 ? 0.001 : 0.0;                       // :195-201
+  else if (eigtrunc > 1.0) return fail("eigtrunc must be between 0 (no truncation) and 1 (keep largest only).");
+  const bool derivative = opt->derivative != 0, vcov_est = opt->vcov_est != 0;
+  std::vector<int64_t> cols;                                                                            // 0-based selected columns
+  if (opt->which_derivatives != nullptr) {                                                              // :206-215
+    if (!derivative) return fail("which.derivative requires derivative = TRUE");
+    for (int64_t i = 0; i < opt->n_which; ++i) {
+      const int64_t w = opt->which_derivatives[i];
+      if (w < 1 || w > p) return fail("which.derivatives must index columns of X");
+      cols.push_back(w - 1);
+    }
+    if (cols.empty()) return fail("which.derivatives must index columns of X");
+  } else {
+    for (int64_t j = 0; j < p; ++j) cols.push_back(j);
+  }
+  const int64_t pd = derivative ? (int64_t)cols.size() : 0;
+  std::vector<double> x_mean(p), x_sd(p);
+  {
+    std::string constant;
+    for (int64_t j = 0; j < p; ++j) {
+      mean_sd(h_X + j * n, n, &x_mean[j], &x_sd[j]);                                                   // :179
+      if (x_sd[j] == 0.0) constant += (constant.empty() ? "" : ", ") + std::to_string(j + 1);
+    }
+    if (!constant.empty())
+      return fail("The following columns in X are constant and must be removed: " + constant);         // :217
+  }
+  for (int64_t i = 0; i < n; ++i)
+    if (std::isnan(h_y[i])) return fail("y contains missing data.");
+  double y_mean = 0.0, y_sd = 0.0;
+  mean_sd(h_y, n, &y_mean, &y_sd);
+  if (y_sd == 0.0) return fail("y is a constant.");
+  if (std::isnan(opt->lambda) || std::isinf(opt->lambda)) return fail("lambda must be a positive scalar");   // :225
+  if (std::isnan(opt->sigma) || std::isinf(opt->sigma)) return fail("sigma must be a positive scalar");      // :227
+  const double sigma = opt->sigma > 0.0 ? opt->sigma : (double)p;                                      // :230
+  if (derivative && !vcov_est)                                                                          // :239
+    return fail("vcov.est is needed to get derivatives (derivative==TRUE requires vcov.est=TRUE).");
+  if (out->binaryindicator) {                                                                           // :242 (raw X)
+    for (int64_t j = 0; j < p; ++j) {
+      double lo, hi;
+      out->binaryindicator[j] = two_valued(h_X + j * n, n, &lo, &hi) ? 1 : 0;
+    }
+  }
+
+  // ---- workspace ---------------------------------------------------------------------------------
+  const int64_t small_doubles = n * p + n * (3 + 3 * std::max<int64_t>(pd, 1)) + 3 * neig + 64;
+  void *psmall = nullptr, *pq = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_FIT_SMALL, small_doubles * (int64_t)sizeof(double), &psmall));
+  BK_TRY(ws_get(ctx, SLOT_FIT_Q, n * neig * (int64_t)sizeof(double), &pq));
+  double* q = (double*)psmall;
+  double* dX = q; q += n * p;
+  double* dy = q; q += n;
+  double* dc = q; q += n;
+  double* dyhat = q; q += n;
+  double* dXe = q; q += n * std::max<int64_t>(pd, 1);
+  double* dD = q; q += n * std::max<int64_t>(pd, 1);
+  double* dS = q; q += n * std::max<int64_t>(pd, 1);
+  double* dvals = q; q += neig;
+  double* da = q; q += neig;
+  double* dw = q; q += neig;
+  double* dQ = (double*)pq;
+  double* dK = out->d_K;
+  if (!dK) {
+    void* pk = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_FIT_K, n * n * (int64_t)sizeof(double), &pk));
+    dK = (double*)pk;
+  }
+  double* pin = nullptr;
+  BK_TRY(pinned_get(ctx, std::max<int64_t>(n * std::max<int64_t>(p, pd) + n, 2 * neig + 64), &pin));
+
+  PhaseTimer timer(ctx);
+  timer.mark();
+  // ---- standardise (R/bigKRLS.R:248-254) straight into the pinned staging buffer, upload ----------
+  for (int64_t j = 0; j < p; ++j) {
+    const double* x = h_X + j * n;
+    double* xs = pin + j * n;
+    const double m = x_mean[j], s = x_sd[j];
+    for (int64_t i = 0; i < n; ++i) xs[i] = (x[i] - m) / s;
+  }
+  double* ys_pin = pin + n * p;
+  for (int64_t i = 0; i < n; ++i) ys_pin[i] = (h_y[i] - y_mean) / y_sd;
+  std::vector<double> Xs(pin, pin + n * p), ys(ys_pin, ys_pin + n);      // host copies for the O(NP) post-processing
+  BK_TRY(upload(ctx, dX, pin, n * p + n));                                // dy follows dX in the slab
+  BK_HIP(hipStreamSynchronize(st));                                       // the pinned buffer is reused below
+  timer.mark();                                                           // h2d
+
+  // ---- step 1: kernel (:262) ----------------------------------------------------------------------
+  BK_TRY(kernel_block(ctx, dX, n, n, dX, n, n, p, sigma, dK, n, 0));
+  timer.mark();                                                           // kernel
+
+  // ---- step 2: eigen (:266-269; bEigen's lastkeeper rule on the device side) ------------------------
+  int64_t lastkeeper = 0;
+  BK_TRY(eigen(ctx, dK, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper));
+  std::vector<double> vals(neig);
+  BK_TRY(download(ctx, vals.data(), dvals, neig, pin));
+  for (int64_t i = 0; i < neig; ++i)
+    if (std::isnan(vals[i]))
+      return fail("Missing eigenvalues prevent bigKRLS from obtaining the regularization parameter lambda.\n\t"
+                  "Check for repeated observations (or other perfect linear combinations in X).");
+  BK_REQUIRE(lastkeeper > 0, "fit: no eigenpair passes the eigtrunc threshold");
+  const int64_t k = lastkeeper;
+  timer.mark();                                                           // eigen
+
+  // ---- step 3: lambda (:271-278; `tol` is never forwarded by the reference: 1e-3 n) -----------------
+  BK_TRY(qty(ctx, dQ, n, k, n, dy, da));
+  double lambda = opt->lambda;
+  int64_t nprobes = 0;
+  if (!(lambda > 0.0)) {
+    if (opt->U >= 0.0 && !(opt->U > 0.0)) return fail("U must be a positive scalar");
+    BK_TRY(lambda_search(ctx, dQ, n, k, n, dvals, da, vals.data(), neig, opt->L, opt->U, -1.0, &lambda, &nprobes,
+                         out->lambda_trace, out->lambda_trace ? out->max_trace : 0));
+  }
+  timer.mark();                                                           // lambda
+  {
+    long double s = 0.0L;
+    for (int64_t i = 0; i < neig; ++i) s += vals[i] / (vals[i] + lambda);                              // :280 (all Neig, Q5)
+    out->Neffective = (double)((long double)n - s);
+  }
+
+  // ---- step 4: coefficients, fitted values (:286-291) -----------------------------------------------
+  double Le = 0.0;
+  BK_TRY(solveforc(ctx, dQ, n, k, n, dvals, da, lambda, dc, &Le));
+  BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                              // yfitted = K c (full K)
+  std::vector<double> coeffs(n), yhat(n);
+  BK_HIP(hipMemcpyAsync(pin, dc, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));        // dyhat follows dc
+  BK_HIP(hipStreamSynchronize(st));
+  std::memcpy(coeffs.data(), pin, (size_t)n * sizeof(double));
+  std::memcpy(yhat.data(), pin + n, (size_t)n * sizeof(double));
+  timer.mark();                                                           // coeffs
+
+  double sigmasq = NaN;
+  std::vector<double> wv(k);
+  if (vcov_est) {
+    long double rs = 0.0L;
+    for (int64_t i = 0; i < n; ++i) {
+      const long double r = (long double)ys[i] - yhat[i];
+      rs += r * r;
+    }
+    sigmasq = (double)(rs / (long double)n);                                                           // :294
+    for (int64_t i = 0; i < k; ++i) wv[i] = sigmasq * std::pow(vals[i] + lambda, -2.0);                // :299
+    const double sd2 = y_sd * y_sd;
+    if (out->d_vcov_c || out->d_vcov_fitted) {
+      void* pm = nullptr;
+      BK_TRY(ws_get(ctx, SLOT_FIT_M, n * k * (int64_t)sizeof(double), &pm));
+      double* dM = (double*)pm;
+      if (out->d_vcov_c) {
+        // vcov.est.c = sd(y)^2 (Q diag(wv)) Q'   (:299-301, :438)
+        std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
+        BK_TRY(upload(ctx, dw, pin, k));
+        BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
+        BK_TRY(gemm(ctx, 0, 1, n, n, k, sd2, dM, n, dQ, n, 0.0, out->d_vcov_c, n));
+        BK_HIP(hipStreamSynchronize(st));
+      }
+      timer.mark();                                                       // vcov_c
+      if (out->d_vcov_fitted) {
+        // :307 crossprod(K, vcovmatc %*% K) == Q diag(wv d^2) Q' on the kept pairs (K Q = Q D):
+        // 2 N^2 K flops instead of 4 N^3
+        for (int64_t i = 0; i < k; ++i) pin[i] = wv[i] * vals[i] * vals[i];
+        BK_TRY(upload(ctx, dw, pin, k));
+        BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
+        BK_TRY(gemm(ctx, 0, 1, n, n, k, sd2, dM, n, dQ, n, 0.0, out->d_vcov_fitted, n));
+        BK_HIP(hipStreamSynchronize(st));
+      }
+      timer.mark();                                                       // vcov_fitted
+    } else {
+      timer.mark();
+      timer.mark();
+    }
+  } else {
+    timer.mark();
+    timer.mark();
+  }
+
+  // ---- step 5: marginal effects (:321-376) and their post-processing (:384-409) -----------------------
+  out->R2AME = NaN;
+  if (derivative) {
+    std::vector<int32_t> isbin(pd);
+    std::vector<double> scale(pd), var(pd);
+    for (int64_t i = 0; i < pd; ++i) {
+      const double* x = Xs.data() + cols[i] * n;
+      std::memcpy(pin + i * n, x, (size_t)n * sizeof(double));                                         // X_estimate (:326)
+      double lo, hi;
+      isbin[i] = two_valued(x, n, &lo, &hi) ? 1 : 0;                                                   // src/bigderiv_v3.cpp:28-31
+      if (isbin[i]) {
+        const double sd = 1.0 / (hi - lo);                                                             // :36
+        scale[i] = 2.0 * sd * sd / ((double)n * (double)n);                                            // :85
+      } else {
+        scale[i] = 4.0 / (sigma * sigma * (double)n * (double)n);                                      // :105
+      }
+    }
+    BK_TRY(upload(ctx, dXe, pin, n * pd));
+    BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n));
+    BK_HIP(hipStreamSynchronize(st));
+    std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
+    BK_TRY(upload(ctx, dw, pin, k));
+    BK_TRY(deriv_var(ctx, dQ, n, k, n, dw, dS, pd, n, scale.data(), var.data()));
+    std::vector<double> D((size_t)n * pd);
+    BK_TRY(download(ctx, D.data(), dD, n * pd, pin));
+    timer.mark();                                                         // derivatives
+    if (out->derivatives_std) std::memcpy(out->derivatives_std, D.data(), D.size() * sizeof(double));
+    if (out->var_avgderivatives_std) std::memcpy(out->var_avgderivatives_std, var.data(), (size_t)pd * sizeof(double));
+    // R2AME in standardised units (:390-392)
+    std::vector<double> dmean(pd), yhat_ame(n, 0.0);
+    for (int64_t i = 0; i < pd; ++i) {
+      long double s = 0.0L;
+      for (int64_t r = 0; r < n; ++r) s += D[(size_t)i * n + r];
+      dmean[i] = (double)(s / (long double)n);
+      const double* x = Xs.data() + cols[i] * n;
+      for (int64_t r = 0; r < n; ++r) yhat_ame[r] += x[r] * dmean[i];
+    }
+    const double c_ame = r_cor(h_y, yhat_ame.data(), n);
+    out->R2AME = c_ame * c_ame;
+    // rescale: D *= sd(y); column i /= X.init.sd[i] -- index i, not which.derivatives[i] (:394-397, quirk Q6)
+    for (int64_t i = 0; i < pd; ++i) {
+      const double f = x_sd[i];
+      double* col = D.data() + (size_t)i * n;
+      long double s = 0.0L;
+      for (int64_t r = 0; r < n; ++r) {
+        col[r] = (y_sd * col[r]) / f;
+        s += col[r];
+      }
+      if (out->avgderivatives) out->avgderivatives[i] = (double)(s / (long double)n);                  // :400
+      if (out->var_avgderivatives) {
+        const double g = y_sd / x_sd[cols[i]];                                                         // :403-407 (correctly subset)
+        out->var_avgderivatives[i] = g * g * var[i];
+      }
+    }
+    if (out->derivatives) std::memcpy(out->derivatives, D.data(), D.size() * sizeof(double));
+  } else {
+    timer.mark();
+  }
+
+  out->Neffective_acf = NaN;
+  if (acf) BK_TRY(neffective(ctx, dX, n, n, p, &out->Neffective_acf));                                 // :412-416
+
+  // ---- the list `w` (:420-469) ---------------------------------------------------------------------------
+  if (out->eigenvalues) std::memcpy(out->eigenvalues, vals.data(), (size_t)neig * sizeof(double));
+  if (out->coeffs) std::memcpy(out->coeffs, coeffs.data(), (size_t)n * sizeof(double));
+  if (out->yfitted_std) std::memcpy(out->yfitted_std, yhat.data(), (size_t)n * sizeof(double));
+  {
+    // yfitted (:428), R2 = 1 - var(y - yfitted)/sd(y)^2 (:429)
+    long double s = 0.0L;
+    std::vector<double> res(n);
+    for (int64_t i = 0; i < n; ++i) {
+      const double yf = yhat[i] * y_sd + y_mean;
+      if (out->yfitted) out->yfitted[i] = yf;
+      res[i] = h_y[i] - yf;
+      s += res[i];
+    }
+    const long double m = s / (long double)n;
+    long double qq = 0.0L;
+    for (int64_t i = 0; i < n; ++i) {
+      const long double dlt = (long double)res[i] - m;
+      qq += dlt * dlt;
+    }
+    out->R2 = 1.0 - (double)(qq / (long double)(n - 1)) / (y_sd * y_sd);
+  }
+  out->lastkeeper = lastkeeper;
+  out->neig = neig;
+  out->n_deriv = pd;
+  out->n_probes = nprobes;
+  out->sigma = sigma;
+  out->lambda = lambda;
+  out->Le = Le;
+  out->Looe = Le * y_sd;                                                                                // :430
+  out->sigmasq = sigmasq;
+  out->y_mean = y_mean;
+  out->y_sd = y_sd;
+  timer.collect(out->phase_s);
+  BK_HIP(hipStreamSynchronize(st));
+  return BIGKRLS_OK;
+}
+
+int bigkrls_predict(bigkrls_ctx* ctx, const double* h_X, int64_t n, int64_t p, const double* h_y,
+                    const double* h_coeffs, double sigma, const double* h_newdata, int64_t u,
+                    const double* d_vcov_c, double neff, double* h_predicted, double* h_se_pred,
+                    double* d_newdataK, double* d_vcov_pred) {
+  BK_TRY(fit_check_ctx(ctx));
+  BK_REQUIRE(h_X && h_y && h_coeffs && h_newdata && h_predicted, "predict: null argument");
+  BK_REQUIRE(n > 1 && p > 0 && u > 0 && sigma > 0.0, "predict: bad dimensions or sigma");
+  const bool want_se = h_se_pred != nullptr || d_vcov_pred != nullptr;
+  if (want_se && !d_vcov_c) {
+    set_error("recompute bigKRLS object with bigKRLS(,vcov.est=TRUE) to compute standard errors");     // R/bigKRLS.R:553
+    return BIGKRLS_EINVAL;
+  }
+  hipStream_t st = ctx->stream;
+  const int64_t small_doubles = n * p + u * p + n + 2 * u + 64;
+  void* psmall = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_FIT_SMALL, small_doubles * (int64_t)sizeof(double), &psmall));
+  double* q = (double*)psmall;
+  double* dX = q; q += n * p;
+  double* dN = q; q += u * p;
+  double* dc = q; q += n;
+  double* dpred = q; q += u;
+  double* ddiag = q; q += u;
+  double* dKn = d_newdataK;
+  if (!dKn) {
+    void* pk = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_FIT_K, u * n * (int64_t)sizeof(double), &pk));
+    dKn = (double*)pk;
+  }
+  double* pin = nullptr;
+  BK_TRY(pinned_get(ctx, n * p + u * p + n + u, &pin));
+  // standardise both with the TRAINING means and sds (R/bigKRLS.R:590-597)
+  for (int64_t j = 0; j < p; ++j) {
+    double m, s;
+    mean_sd(h_X + j * n, n, &m, &s);
+    if (s == 0.0) {
+      set_error("predict: a training column is constant");
+      return BIGKRLS_EINVAL;
+    }
+    const double* x = h_X + j * n;
+    double* xs = pin + j * n;
+    for (int64_t i = 0; i < n; ++i) xs[i] = (x[i] - m) / s;
+    const double* z = h_newdata + j * u;
+    double* zs = pin + n * p + j * u;
+    for (int64_t i = 0; i < u; ++i) zs[i] = (z[i] - m) / s;
+  }
+  std::memcpy(pin + n * p + u * p, h_coeffs, (size_t)n * sizeof(double));
+  BK_HIP(hipMemcpyAsync(dX, pin, (size_t)(n * p + u * p + n) * sizeof(double), hipMemcpyHostToDevice, st));
+  BK_TRY(kernel_block(ctx, dN, u, u, dX, n, n, p, sigma, dKn, u, -1));                                 // bTempKernel (:599)
+  BK_TRY(gemv(ctx, 0, u, n, 1.0, dKn, u, dc, 0.0, dpred));                                            // newdataK %*% coeffs (:601)
+  double y_mean, y_sd;
+  mean_sd(h_y, n, &y_mean, &y_sd);
+  if (want_se) {
+    const double vy = y_sd * y_sd;
+    void* pm = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_FIT_M, (u * n + (d_vcov_pred ? 0 : u * u)) * (int64_t)sizeof(double), &pm));
+    double* dT = (double*)pm;
+    double* dVp = d_vcov_pred ? d_vcov_pred : dT + u * n;
+    // var(y) * tcrossprod(newdataK %*% (vcov.est.c * (1/var(y))), newdataK)   (:608)
+    BK_TRY(gemm(ctx, 0, 0, u, n, n, 1.0 / vy, dKn, u, d_vcov_c, n, 0.0, dT, u));
+    BK_TRY(gemm(ctx, 0, 1, u, u, n, vy, dT, u, dKn, u, 0.0, dVp, u));
+    if (neff > 0.0) BK_TRY(scale(ctx, u * u, std::sqrt((double)n / neff), dVp));                       // :610-611 (quirk Q10)
+    BK_TRY(diag_extract(ctx, dVp, u, u, ddiag));
+  }
+  BK_HIP(hipMemcpyAsync(pin, dpred, (size_t)(want_se ? 2 * u : u) * sizeof(double), hipMemcpyDeviceToHost, st));
+  BK_HIP(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < u; ++i) h_predicted[i] = pin[i] * y_sd + y_mean;                             // :621
+  if (h_se_pred)
+    for (int64_t i = 0; i < u; ++i) h_se_pred[i] = std::sqrt(pin[u + i]);                              // :613
+  return BIGKRLS_OK;
+}
+
+}  // extern "C"

@@ -246,6 +246,82 @@ int bigkrls_dev_scale(bigkrls_ctx* ctx, int64_t n, double alpha, double* x);
 int bigkrls_dev_neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p,
                            double* h_neff);
 
+/* =============================================================================
+ * Level 2, whole-path entry points: the fit and the prediction as ONE call each, so that an R shim
+ * is a single .Call and no N x N object crosses PCIe.
+ * bigkrls_fit() is the numeric body of bigKRLS() (R/bigKRLS.R:175-470: validation, standardisation,
+ * the five steps, rescaling); bigkrls_predict() that of predict.bigKRLS() (R/bigKRLS.R:590-621).
+ * Following the reference's ownership rule, the caller allocates every output -- host arrays for the
+ * small ones, device buffers for K / vcov.est.c / vcov.est.fitted -- and the library writes in place.
+ * ========================================================================== */
+
+typedef struct bigkrls_fit_options {
+  int64_t struct_bytes;      /* sizeof(bigkrls_fit_options); checked                                  */
+  double sigma;              /* <= 0: ncol(X)                                   R/bigKRLS.R:230     */
+  double lambda;             /* <= 0: golden-section search                     :271-278            */
+  double L, U;               /* < 0: derived bounds        R/bigKRLS_Rcpp_functions.R:16-36         */
+  double eigtrunc;           /* < 0: 0.001 if n > 3000 else 0                   :195-201            */
+  int64_t neig;              /* <= 0: n                                         :194                */
+  int32_t derivative;        /* marginal effects (step 5)                       :321                */
+  int32_t vcov_est;          /* variance matrices; derivative != 0 requires it  :239                */
+  int32_t acf;               /* also BigNeffective(X), only when p > 2          :192, :412-416      */
+  int32_t reserved;
+  const int64_t* which_derivatives;  /* 1-based like R; NULL: all columns       :206-215, :326      */
+  int64_t n_which;
+} bigkrls_fit_options;
+
+typedef struct bigkrls_fit_outputs {
+  int64_t struct_bytes;      /* sizeof(bigkrls_fit_outputs); checked */
+  /* ---- caller-allocated host arrays; NULL = not wanted ---------------------------------------- */
+  double* eigenvalues;       /* neig values, descending; ALL are returned (quirk Q5)   :268         */
+  double* coeffs;            /* n                                                       :420         */
+  double* yfitted;           /* n, original units                                       :428         */
+  double* yfitted_std;       /* n, K c in standardised units                            :291         */
+  double* derivatives;       /* n x pd column-major, rescaled incl. quirk Q6            :394-397     */
+  double* derivatives_std;   /* n x pd, as BigDerivMat returns them                     :329         */
+  double* avgderivatives;    /* pd                                                      :400         */
+  double* var_avgderivatives;      /* pd                                                :403-407     */
+  double* var_avgderivatives_std;  /* pd, before the rescaling                                        */
+  int32_t* binaryindicator;  /* p flags: column has exactly two distinct values         :242         */
+  double* lambda_trace;      /* 2 x max_trace: (lambda_t, Le_t) of every probe of the search          */
+  int64_t max_trace;
+  /* ---- caller-allocated DEVICE buffers, n x n column-major (ld = n); NULL = not returned ------- */
+  double* d_K;               /* the kernel                                              :434         */
+  double* d_vcov_c;          /* sd(y)^2 V                                               :438         */
+  double* d_vcov_fitted;     /* sd(y)^2 V_yhat                                          :445         */
+  /* ---- scalars written by the call ---------------------------------------------------------------- */
+  int64_t lastkeeper;        /* kept eigenpairs        R/bigKRLS_Rcpp_functions.R:190                */
+  int64_t neig;              /* length of `eigenvalues` */
+  int64_t n_deriv;           /* pd: ncol of the derivative outputs */
+  int64_t n_probes;          /* probes of the lambda search (0 when lambda was given) */
+  double sigma, lambda;
+  double Le, Looe;           /* leave-one-out loss, standardised and x sd(y)            :430         */
+  double sigmasq;            /* ||y - yhat||^2 / n                                       :294         */
+  double R2, R2AME;          /*                                                         :429, :392   */
+  double Neffective;         /* n - sum_{all Neig} d/(d+lambda)                         :280         */
+  double Neffective_acf;     /* NaN unless options.acf                                   :412-416     */
+  double y_mean, y_sd;
+  double phase_s[8];         /* HIP-event seconds: h2d, kernel, eigen, lambda, coeffs, vcov_c,
+                                vcov_fitted, derivatives */
+} bigkrls_fit_outputs;
+
+/* X is n x p column-major, y has n entries, both on the HOST (they are small: 8 n (p+1) bytes).
+ * Errors of the reference's validation block (:183-240) come back as BIGKRLS_EINVAL with R's own
+ * message text in bigkrls_last_error(). */
+int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                const bigkrls_fit_options* options, bigkrls_fit_outputs* out);
+
+/* predict.bigKRLS (R/bigKRLS.R:590-621): newdata (u x p, host) is standardised with the TRAINING
+ * means and sds, the u x n test kernel is built, predicted = K_new c sd(y) + mean(y).
+ * With d_vcov_c (the fit's device-resident vcov.est.c) and h_se_pred or d_vcov_pred given, also
+ * vcov.est.pred = var(y) K_new (vcov.est.c / var(y)) K_new' (:608), times sqrt(n / neffective) when
+ * neffective > 0 (correct.SE, quirk Q10, :610-611), and se.pred = sqrt(diag) (:613).
+ * d_newdataK (u x n) and d_vcov_pred (u x u) are optional caller-allocated device outputs. */
+int bigkrls_predict(bigkrls_ctx* ctx, const double* h_X, int64_t n, int64_t p, const double* h_y,
+                    const double* h_coeffs, double sigma, const double* h_newdata, int64_t u,
+                    const double* d_vcov_c, double neffective,
+                    double* h_predicted, double* h_se_pred, double* d_newdataK, double* d_vcov_pred);
+
 #ifdef __cplusplus
 }
 #endif

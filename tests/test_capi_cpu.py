@@ -119,3 +119,41 @@ def test_column_major_filler_matches_fortran_flattening():
     dst = np.empty(view.size)
     _column_major_filler(view)(dst, 0, view.size)
     assert np.array_equal(dst, view.reshape(-1, order="F"))
+
+
+def test_fit_struct_layout_matches_the_header(tmp_path):
+    """bigkrls_fit_options / bigkrls_fit_outputs as ctypes sees them vs as a C compiler lays them
+    out from include/bigkrls.h (sizes and the offsets of the first scalar output and phase_s)."""
+    import subprocess
+    from bigkrls_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bigkrls.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(bigkrls_fit_options), '
+                   'sizeof(bigkrls_fit_outputs), offsetof(bigkrls_fit_outputs, lastkeeper), '
+                   'offsetof(bigkrls_fit_outputs, phase_s), offsetof(bigkrls_fit_options, which_derivatives));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(t) for t in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(_lib.FitOptions), C.sizeof(_lib.FitOutputs), _lib.FitOutputs.lastkeeper.offset,
+            _lib.FitOutputs.phase_s.offset, _lib.FitOptions.which_derivatives.offset]
+    assert got == want
+
+
+def test_plain_c_caller_builds_and_fails_loudly_without_gpu():
+    """tests/capi/fit_example.c, a C99 caller of bigkrls_fit / bigkrls_predict compiled with gcc against
+    include/bigkrls.h (what an R shim's body does): it must build, link and -- without a GPU --
+    return BIGKRLS_ENODEVICE instead of computing anything."""
+    import subprocess
+    import torch
+    from bigkrls_amd import _lib
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "capi")], check=True, capture_output=True)
+    _lib.load()
+    ex = C.CDLL(os.path.join(ROOT, "tests", "capi", "libfit_example.so"))
+    ex.capi_fit_example.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: exercised by tests/test_gpu_fit_capi.py")
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((40, 3)))
+    y = np.ascontiguousarray(X[:, 0] + 0.1)
+    coeffs, res = np.zeros(40), np.zeros(8)
+    st = ex.capi_fit_example(X.ctypes.data, y.ctypes.data, 40, 3, 5, coeffs.ctypes.data, res.ctypes.data)
+    assert st == _lib.ENODEVICE and not coeffs.any() and not res.any()
