@@ -75,11 +75,14 @@ def kept_subspace_checks(ctx, ops, out, K, Q, ys, n):
 
 def derivative_identities(ctx, ops, out, K, Xs, cols, sigma):
     """Continuous columns: D_j = (-2/sigma) (x_j o Kc - K (x_j o c)) (src/bigderiv_v3.cpp:90-103 in its
-    O(N^2) form) recomputed with plain matvecs, independent of the fused derivative kernel."""
+    O(N^2) form) recomputed with plain matvecs, independent of the fused derivative kernel.
+    `cols` are 0-based columns of X; with which.derivatives the outputs hold only the selected ones."""
     c = out["coeffs"]
     Kc = out["yfitted.std"]
     D = out["derivatives.std"]
-    for i, j in enumerate(cols):
+    which = out["which.derivatives"]
+    for j in cols:
+        i = j if which is None else which.index(j + 1)
         x = Xs[:, j]
         Kxc = ops.matvec(K, ctx.from_numpy(x * c)).to_numpy().ravel()
         assert rel(D[:, i], (-2.0 / sigma) * (x * Kc - Kxc)) < 1e-9, j
