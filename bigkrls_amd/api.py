@@ -381,14 +381,75 @@ def predict(object: BigKRLS, newdata, se_pred=False, correct_SE=True, ytest=None
     return out
 
 
+def _run_folds(jobs, contexts, fit_fn, predict_fn):
+    """Run independent (train, test) jobs, one worker thread per context (== per GPU), and return
+    the results in job order. Fold k goes to context k mod G: a fixed assignment, and because every
+    kernel is deterministic the result of a fold does not depend on which GPU computed it. The
+    native calls release the GIL (ctypes), a context serves one thread at a time (include/bigkrls.h,
+    "Threading"), and HIP's current device is per thread -- no process is spawned, so this is safe
+    in a process that has already initialised the GPU."""
+    import threading
+    results = [None] * len(jobs)
+    errors = []
+
+    def worker(slot):
+        cx = contexts[slot]
+        try:
+            if hasattr(cx, "torch"):
+                cx.torch.cuda.set_device(cx.device_index)          # thread-local current device
+            for j in range(slot, len(jobs), len(contexts)):
+                results[j] = jobs[j](cx, fit_fn, predict_fn)
+        except BaseException as e:                                 # re-raised in the caller's thread
+            errors.append(e)
+
+    if len(contexts) == 1:
+        worker(0)
+    else:
+        threads = [threading.Thread(target=worker, args=(g,), name=f"bigkrls-fold-gpu{g}") for g in range(len(contexts))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
+def _fold_contexts(ctx, devices):
+    """One context per requested GPU. `devices`: None (the given / default context only), "all",
+    or a list of device indices (or of ready-made contexts)."""
+    if devices is None:
+        return [ctx or default_context()]
+    import torch
+    if devices == "all":
+        devices = list(range(torch.cuda.device_count()))
+    devices = list(devices)
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
+    out = []
+    for d in devices:
+        if not isinstance(d, (int, np.integer)):                   # a ready-made context
+            out.append(d)
+        elif ctx is not None and ctx.device_index == int(d) and ctx not in out:
+            out.append(ctx)
+        else:
+            out.append(Context(int(d)))
+    return out
+
+
 def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, folds=None,
-                  ctx: Optional[Context] = None, **fit_args) -> Dict[str, object]:
+                  ctx: Optional[Context] = None, devices=None, **fit_args) -> Dict[str, object]:
     """crossvalidate.bigKRLS (R/bigKRLS.R:1146-1336).
 
     R partitions with set.seed(seed); sample() (:1168,1179,1232), a stream that
     cannot be reproduced without R, so the partition can be supplied explicitly:
     `train_idx` (0-based rows, ptesting branch) or `folds` (label 1..Kfolds per
     row, Kfolds branch).  Without them numpy's default_rng(seed) draws one.
+
+    `devices` (None, "all" or a list of GPU indices): the folds of the Kfolds branch are whole,
+    independent fits (the loop at :1268-1282), so they run as replicas, one fold per GPU at a time
+    (last row): one context and one worker thread per GPU, no data-path
+    collective. The statistics are identical to the sequential loop's.
     """
     if (Kfolds is None) + (ptesting is None) != 1:
         raise ValueError("Specify either Kfolds or ptesting but not both.")
@@ -398,9 +459,9 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
     marginals = fit_args.get("derivative", True)
     rng = np.random.default_rng(seed)
 
-    def one_split(tr, te):
-        trained = bigKRLS(yh[tr], Xh[tr], ctx=ctx, **fit_args)
-        tested = predict(trained, Xh[te])
+    def one_split(tr, te, cx, fit_fn, predict_fn):
+        trained = fit_fn(yh[tr], Xh[tr], ctx=cx, **fit_args)
+        tested = predict_fn(trained, Xh[te])
         ytest = yh[te]
         tested["ytest"] = ytest
         r = {"trained": trained, "tested": tested}
@@ -417,6 +478,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
             r["MSE_AME_oos"] = float(np.mean((ytest - yhat_ame) ** 2))            # :1213
         return r
 
+    contexts = _fold_contexts(ctx, devices)
     if ptesting is not None:
         if ptesting < 0 or ptesting > 100:
             raise ValueError("ptesting, the percentage of data to be used for validation, must be between 0 and 100.")
@@ -426,7 +488,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
             train_idx = rng.choice(N, Ntraining, replace=False)
         tr = np.asarray(train_idx)
         te = np.setdiff1d(np.arange(N), tr)
-        out = one_split(tr, te)
+        out = one_split(tr, te, contexts[0], _cv_fit, _cv_predict)
         out.update(type="crossvalidated", seed=seed, ptesting=ptesting,
                    indices={"train.set": tr, "test.set": te})
         return out
@@ -445,10 +507,15 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
         keys += ["R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos"]
     for k in keys:
         out[k] = []
-    for k in range(1, Kfolds + 1):
+
+    def job(k):
         tr = np.nonzero(folds != k)[0]
         te = np.nonzero(folds == k)[0]
-        r = one_split(tr, te)
+        return lambda cx, fit_fn, predict_fn: one_split(tr, te, cx, fit_fn, predict_fn)
+
+    results = _run_folds([job(k) for k in range(1, Kfolds + 1)], contexts, _cv_fit, _cv_predict)
+    out["devices"] = [getattr(c, "device_index", None) for c in contexts]
+    for k, r in zip(range(1, Kfolds + 1), results):
         out[f"fold_{k}"] = r
         out["R2_is"].append(r["pseudoR2_is"])
         out["R2_oos"].append(r["pseudoR2_oos"])
@@ -460,3 +527,9 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
             out["MSE_AME_is"].append(r["MSE_AME_is"])
             out["MSE_AME_oos"].append(r["MSE_AME_oos"])
     return out
+
+
+# the fit / predict the cross-validation driver calls (module-level so that the CPU tests of the fold
+# scheduler can substitute doubles that need no GPU)
+_cv_fit = bigKRLS
+_cv_predict = predict

@@ -54,9 +54,16 @@ def _column_major_filler(a: np.ndarray):
 
 
 class Context:
-    """One GPU, one HIP stream (torch's current stream), one workspace pool."""
+    """One GPU, one HIP stream, one workspace pool.
 
-    def __init__(self, device: Optional[int] = None):
+    The stream is torch's current stream of the device at construction (so tensors made elsewhere
+    on that stream are ordered with the library's kernels) or, with `own_stream=True`, a new stream
+    of this context (several contexts on one device, e.g. one per worker thread). Every allocation
+    and transfer of this context is issued with that stream as torch's current one, whatever the
+    caller's current stream or thread is: the caching allocator then orders re-use of a freed block
+    against the stream the library actually launches on."""
+
+    def __init__(self, device: Optional[int] = None, own_stream: bool = False):
         import torch
 
         if not torch.cuda.is_available():
@@ -65,9 +72,9 @@ class Context:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         torch.cuda.set_device(self.device_index)
         self.device = torch.device("cuda", self.device_index)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.stream = torch.cuda.Stream(self.device) if own_stream else torch.cuda.current_stream(self.device)
         h = C.c_void_p()
-        _lib.call("bigkrls_ctx_create_on_stream", self.device_index, C.c_void_p(stream), C.byref(h))
+        _lib.call("bigkrls_ctx_create_on_stream", self.device_index, C.c_void_p(self.stream.cuda_stream), C.byref(h))
         self.handle = h
         self._events = []
         self._stage = None
@@ -105,12 +112,18 @@ class Context:
         return float(ms.value), float(work.value), int(n.value)
 
     # ---- allocation ---------------------------------------------------------
+    def on_stream(self):
+        """`with ctx.on_stream():` -- torch work inside is issued on the context's stream."""
+        return self.torch.cuda.stream(self.stream)
+
     def empty(self, nrow: int, ncol: int = 1) -> "DeviceMatrix":
-        t = self.torch.empty((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)
+        with self.on_stream():
+            t = self.torch.empty((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)
         return DeviceMatrix(self, t)
 
     def zeros(self, nrow: int, ncol: int = 1) -> "DeviceMatrix":
-        t = self.torch.zeros((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)
+        with self.on_stream():
+            t = self.torch.zeros((int(ncol), int(nrow)), dtype=self.torch.float64, device=self.device)
         return DeviceMatrix(self, t)
 
     # ---- transfers ------------------------------------------------------------
@@ -139,16 +152,17 @@ class Context:
         pieces = self._pieces(n)
         stage, snp = self._stage, self._stage_np
         done = [None, None]
-        for i, (off, m, so) in enumerate(pieces):
-            if done[i % 2] is not None:
-                done[i % 2].synchronize()       # this half's previous copy has left the host
-            fill(snp[so:so + m], off, m)
-            flat_dev[off:off + m].copy_(stage[so:so + m], non_blocking=True)
-            done[i % 2] = self.torch.cuda.Event()
-            done[i % 2].record()
-        for e in done:
-            if e is not None:
-                e.synchronize()
+        with self.on_stream():
+            for i, (off, m, so) in enumerate(pieces):
+                if done[i % 2] is not None:
+                    done[i % 2].synchronize()       # this half's previous copy has left the host
+                fill(snp[so:so + m], off, m)
+                flat_dev[off:off + m].copy_(stage[so:so + m], non_blocking=True)
+                done[i % 2] = self.torch.cuda.Event()
+                done[i % 2].record()
+            for e in done:
+                if e is not None:
+                    e.synchronize()
 
     def download(self, t) -> np.ndarray:
         """Host copy (C order, same shape) of a contiguous device tensor."""
@@ -160,19 +174,20 @@ class Context:
         pieces = self._pieces(n)
         stage, snp = self._stage, self._stage_np
         events = []
-        for i, (off, m, so) in enumerate(pieces):
-            if i >= 2:                          # the half is free once its previous piece is on the host
-                poff, pm, pso = pieces[i - 2]
-                events[i - 2].synchronize()
+        with self.on_stream():
+            for i, (off, m, so) in enumerate(pieces):
+                if i >= 2:                          # the half is free once its previous piece is on the host
+                    poff, pm, pso = pieces[i - 2]
+                    events[i - 2].synchronize()
+                    out[poff:poff + pm] = snp[pso:pso + pm]
+                stage[so:so + m].copy_(flat[off:off + m], non_blocking=True)
+                e = self.torch.cuda.Event()
+                e.record()
+                events.append(e)
+            for i in range(max(0, len(pieces) - 2), len(pieces)):
+                poff, pm, pso = pieces[i]
+                events[i].synchronize()
                 out[poff:poff + pm] = snp[pso:pso + pm]
-            stage[so:so + m].copy_(flat[off:off + m], non_blocking=True)
-            e = self.torch.cuda.Event()
-            e.record()
-            events.append(e)
-        for i in range(max(0, len(pieces) - 2), len(pieces)):
-            poff, pm, pso = pieces[i]
-            events[i].synchronize()
-            out[poff:poff + pm] = snp[pso:pso + pm]
         return out.reshape(tuple(t.shape))
 
     def from_numpy(self, a: np.ndarray) -> "DeviceMatrix":
@@ -181,7 +196,8 @@ class Context:
             a = a[:, None]
         nrow, ncol = a.shape
         # (ncol, nrow) C-contiguous == (nrow, ncol) column-major
-        t = self.torch.empty((ncol, nrow), dtype=self.torch.float64, device=self.device)
+        with self.on_stream():
+            t = self.torch.empty((ncol, nrow), dtype=self.torch.float64, device=self.device)
         fill = _column_major_filler(a)
         self.upload_into(t.view(-1), fill)
         return DeviceMatrix(self, t)
@@ -245,13 +261,16 @@ class DeviceMatrix:
 
     def to_numpy(self) -> np.ndarray:
         # (ncol, nrow) C order is (nrow, ncol) column-major: return the Fortran-ordered view
-        return self.ctx.download(self.t.contiguous()).T
+        with self.ctx.on_stream():
+            t = self.t.contiguous()
+        return self.ctx.download(t).T
 
     def __getitem__(self, idx):  # R's `K[]` idiom: materialise on the host
         return self.to_numpy()[idx]
 
     def copy(self) -> "DeviceMatrix":
-        return DeviceMatrix(self.ctx, self.t.clone())
+        with self.ctx.on_stream():
+            return DeviceMatrix(self.ctx, self.t.clone())
 
     def scale_(self, alpha: float) -> "DeviceMatrix":
         _lib.call("bigkrls_dev_scale", self.ctx.handle, self.nrow * self.ncol, float(alpha), self.ptr)

@@ -26,6 +26,37 @@ import numpy as np
 from .api import BigKRLS, BigKRLSPredicted, default_context
 from .device import Context, is_device_matrix
 
+
+def write_big_matrix_text(host: np.ndarray, path: str, digits: int = 17) -> None:
+    """The text layout of bigmemory's `write.big.matrix(x, filename)` as bSave calls it
+    (R/bigKRLS_Rcpp_functions.R:306-307; defaults sep = ",", no row or column names): one matrix row
+    per line, values joined by commas, every value printed the way a C++ ostream with
+    `precision(16)` prints a double (printf's %.16g; bigmemory's `ttos`), NA for missing values,
+    "\n" line ends. bigmemory is a third-party dependency absent from /root/reference (4.5.19 in the
+    reference's recorded session, examples/numeric_convergence.md:68-95); the layout is pinned by the
+    hand-written fixture tests/golden/write_big_matrix_3x4.txt. `digits=16` reproduces bigmemory's
+    files byte for byte; the default 17 keeps the same layout but round-trips every double exactly
+    (16 digits lose the last bit of some values, which is why the reference's own reload test only
+    asks for max(K - K2) < 1e-6, tests/testthat/test_basic_usage.R:123-128)."""
+    host = np.atleast_2d(np.asarray(host, dtype=np.float64))
+    if not np.isnan(host).any():
+        np.savetxt(path, host, delimiter=",", fmt=f"%.{int(digits)}g", newline="\n")
+        return
+    spec = f".{int(digits)}g"
+    with open(path, "w", newline="\n") as f:
+        for row in host:
+            f.write(",".join("NA" if np.isnan(v) else format(v, spec) for v in row) + "\n")
+
+
+def read_big_matrix_text(path: str) -> np.ndarray:
+    """`read.big.matrix(path, type = "double")` as bLoad calls it (R/bigKRLS_Rcpp_functions.R:359-360):
+    comma separated, no header, NA -> NaN."""
+    try:
+        return np.atleast_2d(np.loadtxt(path, delimiter=",", dtype=np.float64))
+    except ValueError:      # NA tokens: the slower tolerant reader
+        return np.atleast_2d(np.genfromtxt(path, delimiter=",", dtype=np.float64, missing_values="NA",
+                                           filling_values=np.nan))
+
 _BIGKRLS_MATRICES = ["K", "X", "derivatives", "vcov.est.c", "vcov.est.fitted"]             # bLoad :337
 _PREDICTED_MATRICES = ["predicted", "se.pred", "vcov.est.pred", "newdata", "newdataK", "ytest"]   # :340
 
@@ -45,7 +76,7 @@ def _make_path(folder: str, overwrite_existing: bool) -> str:
 
 
 def save_bigKRLS(object, model_subfolder_name: str, overwrite_existing: bool = False, noisy: bool = True,
-                 binary: bool = False) -> str:
+                 binary: bool = False, digits: int = 17) -> str:
     if not isinstance(object, (BigKRLS, BigKRLSPredicted)):
         raise TypeError("Object not a bigKRLS class.")
     if not isinstance(model_subfolder_name, str):
@@ -63,7 +94,7 @@ def save_bigKRLS(object, model_subfolder_name: str, overwrite_existing: bool = F
             if binary:
                 np.save(path, np.asfortranarray(host))
             else:
-                np.savetxt(path, host, delimiter=",", fmt="%.17g")
+                write_big_matrix_text(host, path, digits=digits)
             nbm += 1
         elif val is None:
             meta["none"].append(name)
@@ -115,8 +146,7 @@ def load_bigKRLS(path: str, noisy: bool = True, ctx: Optional[Context] = None, t
             continue
         if noisy:
             print("\tReading from", npy if npy in files else txt)
-        host = np.load(os.path.join(path, npy)) if npy in files else \
-            np.atleast_2d(np.loadtxt(os.path.join(path, txt), delimiter=",", dtype=np.float64))
+        host = np.load(os.path.join(path, npy)) if npy in files else read_big_matrix_text(os.path.join(path, txt))
         if to_device:
             ctx = ctx or default_context()
             obj[name] = ctx.from_numpy(host)

@@ -300,3 +300,27 @@ def test_dist_path_sharded_block_lanczos_world1(ctx):
     assert rel(out["K.eigenvalues"], one["K.eigenvalues"]) < 1e-9
     for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives"):
         assert rel(out[k], one[k]) < TOL, k
+
+
+@pytest.mark.gpu
+def test_crossvalidate_fold_parallel_contexts(ctx):
+    """Fold-parallel crossvalidate (SURVEY 8(e) "replicas only": whole folds, one per GPU at a time;
+    the reference's loop is R/bigKRLS.R:1268-1282). On the one GPU of this box: (i) devices=[0] goes
+    through the worker path and equals the sequential loop and the oracle; (ii) two contexts with
+    their own streams on device 0, one worker thread each -- the multi-GPU code path with both
+    "GPUs" being the same device -- give the same statistics, fold for fold."""
+    import bigkrls_amd as bk
+    X, y = orc.synth(600, 4, 49, binary_last=True)
+    folds = (np.arange(600) % 4) + 1
+    ref = orc.crossvalidate_kfolds(y, X, folds, literal=False)
+    seq = bk.crossvalidate(y, X, Kfolds=4, folds=folds, ctx=ctx)
+    one = bk.crossvalidate(y, X, Kfolds=4, folds=folds, ctx=ctx, devices=[0])
+    two = bk.crossvalidate(y, X, Kfolds=4, folds=folds,
+                           devices=[bk.Context(0, own_stream=True), bk.Context(0, own_stream=True)])
+    assert one["devices"] == [0] and two["devices"] == [0, 0]
+    for k in ["R2_is", "R2_oos", "MSE_is", "MSE_oos", "R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos"]:
+        assert rel(seq[k], ref[k]) < TOL, k
+        assert one[k] == seq[k], k
+        assert two[k] == seq[k], k                      # deterministic kernels: bitwise the same on any context
+    c0 = two["fold_1"]["trained"]["_ctx"]
+    assert two["fold_3"]["trained"]["_ctx"] is c0 and two["fold_2"]["trained"]["_ctx"] is not c0

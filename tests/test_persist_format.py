@@ -1,0 +1,43 @@
+"""The text layout of the big.matrix members that save.bigKRLS writes (bSave,
+R/bigKRLS_Rcpp_functions.R:300-311 -> bigmemory::write.big.matrix) and load.bigKRLS reads (bLoad,
+:330-379 -> read.big.matrix), pinned against a HAND-WRITTEN fixture in that layout:
+tests/golden/write_big_matrix_3x4.txt -- comma separated, no header, one matrix row per line,
+16 significant digits the way a C++ ostream prints them (1e-05, 1e+20, integers without a point),
+NA for a missing value. bigmemory itself is third-party and absent; see persist.write_big_matrix_text."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "write_big_matrix_3x4.txt")
+EXPECTED = np.array([[1.0, 0.5, 1.0 / 3.0, 1e-5],
+                     [2.0, -np.exp(-2.0), 1234567.890123457, np.nan],
+                     [3.0, 1e20, 0.0, -np.finfo(float).eps]])
+
+
+def test_reader_parses_the_write_big_matrix_fixture():
+    from bigkrls_amd.persist import read_big_matrix_text
+    got = read_big_matrix_text(FIXTURE)
+    assert got.shape == (3, 4)
+    assert np.isnan(got[1, 3])
+    mask = ~np.isnan(EXPECTED)
+    # 16 significant digits: equal to within one unit in the 16th digit, most values exactly
+    assert np.allclose(got[mask], EXPECTED[mask], rtol=2e-16, atol=0)
+    assert got[0, 2] == float("0.3333333333333333") and got[2, 3] == -2.220446049250313e-16
+
+
+def test_writer_reproduces_the_fixture_byte_for_byte(tmp_path):
+    from bigkrls_amd.persist import read_big_matrix_text, write_big_matrix_text
+    out = tmp_path / "m.txt"
+    write_big_matrix_text(EXPECTED, str(out), digits=16)            # bigmemory's precision(16)
+    assert out.read_bytes() == open(FIXTURE, "rb").read()
+    # the default (17 digits): same layout, and every double survives the round trip exactly
+    rng = np.random.default_rng(0)
+    M = np.exp(-rng.random((7, 5)) * 30) * rng.choice([-1, 1], (7, 5))
+    write_big_matrix_text(M, str(out))
+    assert np.array_equal(read_big_matrix_text(str(out)), M)
+    lines = out.read_text().split("\n")
+    assert len(lines) == 8 and lines[-1] == "" and all(len(l.split(",")) == 5 for l in lines[:-1])
+    # a single column / single row keep their shape (read.big.matrix returns a matrix)
+    write_big_matrix_text(M[:, :1], str(out))
+    assert read_big_matrix_text(str(out)).reshape(-1).tolist() == M[:, 0].tolist()
