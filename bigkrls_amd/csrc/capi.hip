@@ -264,6 +264,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (!ctx) return BIGKRLS_OK;
   (void)hipSetDevice(ctx->device);
   (void)bigkrls_ctx_release_workspace(ctx);
+  if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -418,6 +419,47 @@ int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t
   BK_TRY(check_ctx(ctx));
   return eigen(ctx, A, n, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
                part_count);
+}
+
+int bigkrls_dev_s1_open(bigkrls_ctx* ctx, int64_t n) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_open(ctx, n);
+}
+
+int bigkrls_dev_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_panel(ctx, n, k, strip);
+}
+
+int bigkrls_dev_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda,
+                      int64_t ncols, double* Yout, int64_t ldy) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_av(ctx, n, k, Acols, lda, ncols, Yout, ldy);
+}
+
+int bigkrls_dev_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda,
+                          int64_t ncols, int64_t row0) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_update(ctx, n, k, Y, Acols, lda, ncols, row0);
+}
+
+int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_put(ctx, n, k, strip, ncols);
+}
+
+int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals, int64_t n_vecs_max,
+                             double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
+                             int32_t part_index, int32_t part_count) {
+  BK_TRY(check_ctx(ctx));
+  return eigen(ctx, nullptr, n, n, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
+               part_count, EIG_RESUME);
+}
+
+int bigkrls_dev_copy_matrix(bigkrls_ctx* ctx, const double* src, int64_t m, int64_t n, int64_t lds,
+                            double* dst, int64_t ldd) {
+  BK_TRY(check_ctx(ctx));
+  return copy_matrix(ctx, src, m, n, lds, dst, ldd);
 }
 
 int bigkrls_dev_qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,

@@ -55,6 +55,9 @@ struct bigkrls_ctx {
   // set while a decomposition is retried after the watchdog of a persistent kernel fired: the
   // panel QR runs one launch per column and the bulge chasing one launch per wavefront
   bool no_resident = false;
+  // state of a row-block distributed stage 1 between bigkrls_dev_s1_open and bigkrls_dev_eigen_resume
+  void* dist_s1 = nullptr;
+  void (*dist_s1_free)(void*) = nullptr;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
@@ -188,8 +191,20 @@ int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t l
               double* h_var);
 
 // ---- eigen.hip ----------------------------------------------------------------
+// mode: EIG_FULL decomposes A; EIG_SETUP_ONLY only lays out the workspace of the two-stage path
+// (used by the distributed stage 1); EIG_RESUME continues after an externally driven stage 1.
+enum EigMode { EIG_FULL = 0, EIG_SETUP_ONLY = 1, EIG_RESUME = 2 };
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
-          int part_index = 0, int part_count = 1);
+          int part_index = 0, int part_count = 1, int mode = EIG_FULL);
+// Row-block distributed stage 1 (dense -> band), one call per panel step between the caller's
+// collectives; see include/bigkrls.h (bigkrls_dev_s1_*).
+int dist_s1_open(bigkrls_ctx* ctx, int64_t n);
+int dist_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
+int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda, int64_t ncols,
+               double* Yout, int64_t ldy);
+int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
+                   int64_t row0);
+int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
 
 }  // namespace bk

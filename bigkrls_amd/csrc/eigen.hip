@@ -1703,7 +1703,7 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
 
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
-          int part_index, int part_count);
+          int part_index, int part_count, int mode);
 
 static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t k, double* vals,
                         int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
@@ -1791,7 +1791,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
       BK_HIP(hipMemcpyAsync(dT, T.data(), (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, st));
       BK_HIP(hipStreamSynchronize(st));
       int64_t nvY = 0;
-      BK_TRY(eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1));
+      BK_TRY(eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1, EIG_FULL));
       theta.resize(m);
       BK_HIP(hipMemcpy(theta.data(), dvalsT, m * sizeof(double), hipMemcpyDeviceToHost));
       double worst = 0.0;
@@ -1855,7 +1855,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
   void* pZ = nullptr;
   BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
   int64_t nvZ = 0;
-  BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1));
+  BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1, EIG_FULL));
   std::vector<double> hv(k);
   BK_HIP(hipMemcpy(hv.data(), dvalsH, k * sizeof(double), hipMemcpyDeviceToHost));
   BK_HIP(hipMemcpyAsync(vals, dvalsH, k * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1895,20 +1895,31 @@ static int eigen_retry_without_resident(bigkrls_ctx* ctx, const double* A, int64
     fprintf(stderr, "[bigkrls] eigen: persistent-kernel watchdog fired; retrying with per-step launches\n");
   ctx->no_resident = true;
   const int rc = eigen(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
-                       part_count);
+                       part_count, EIG_FULL);
   ctx->no_resident = false;
   return rc;
 }
 
+// Stage-1 state of a row-block distributed reduction, kept in the context between
+// bigkrls_dev_s1_open and bigkrls_dev_eigen_resume.
+struct DistS1 {
+  S1Ops ops;
+  int n = 0;
+};
+
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
-          int part_index, int part_count) {
+          int part_index, int part_count, int mode) {
   BK_REQUIRE(part_count >= 1 && part_index >= 0 && part_index < part_count, "eigen: bad column partition");
-  BK_REQUIRE(A && vals && n64 > 0 && n64 < (1ll << 30), "eigen: bad matrix");
-  BK_REQUIRE(n_vals > 0 && n_vals <= n64, "eigen: n_vals out of range");
-  BK_REQUIRE(n_vecs_max >= 0 && n_vecs_max <= n64, "eigen: n_vecs_max out of range");
-  BK_REQUIRE(n_vecs_max == 0 || (vecs && ldv >= n64), "eigen: bad eigenvector buffer");
-  {
+  BK_REQUIRE(n64 > 0 && n64 < (1ll << 30), "eigen: bad matrix");
+  if (mode != EIG_SETUP_ONLY) {
+    BK_REQUIRE((A || mode == EIG_RESUME) && vals, "eigen: bad matrix");
+    BK_REQUIRE(n_vals > 0 && n_vals <= n64, "eigen: n_vals out of range");
+    BK_REQUIRE(n_vecs_max >= 0 && n_vecs_max <= n64, "eigen: n_vecs_max out of range");
+    BK_REQUIRE(n_vecs_max == 0 || (vecs && ldv >= n64), "eigen: bad eigenvector buffer");
+  }
+  if (mode != EIG_FULL) BK_REQUIRE(n64 > 4 * S2_B, "eigen: the distributed dense path needs n > 256");
+  if (mode == EIG_FULL) {
     // Neig << N: block Lanczos (the reference switches to eigs_sym for Neig < N, src/eigen.cpp:18-22);
     // BIGKRLS_EIGK=dense keeps the dense path, =krylov forces the iterative one when Neig <= N/4
     const char* ek = getenv("BIGKRLS_EIGK");
@@ -1950,7 +1961,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   double* e = d + N;
   double* tau = e + N;
   double* scratch = tau + N;
-  BK_TRY(copy_matrix(ctx, A, N, N, lda, W, N));
+  if (mode == EIG_FULL) BK_TRY(copy_matrix(ctx, A, N, N, lda, W, N));
   BK_HIP(hipMemsetAsync(d, 0, 3 * N * sizeof(double), st));
   // tiled-symv partial buffers live in the (later) U slot of the divide & conquer
   const int64_t sv_prow = (N / SV_CW + 2) * N, sv_pcol = 10 * N, sv_prow2 = (N / (SV_CW * 32) + 2) * N;
@@ -1961,7 +1972,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   // two-stage (band) reduction is the default above 4 panels; BIGKRLS_EIG=1stage forces the
   // one-stage (symv) reduction (kept for small n and as a cross-check: the tests run both)
   const char* eig_env = getenv("BIGKRLS_EIG");
-  const bool two_stage = !(eig_env && std::string(eig_env) == "1stage") && n > 4 * S2_B;
+  const bool two_stage = mode != EIG_FULL || (!(eig_env && std::string(eig_env) == "1stage") && n > 4 * S2_B);
   double *taus1 = nullptr, *AB = nullptr, *VV = nullptr, *TT = nullptr;
   int64_t* d_soff = nullptr;
   std::vector<int64_t> bt2_toff;      // (source of an asynchronous copy: lives until the function returns)
@@ -1993,8 +2004,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     s1.mail = s1.part + (npart - nmail);
     s1.mail2 = s1.mail + nmail1;
     s1.err = (int*)scratch;
-    BK_HIP(hipMemsetAsync(s1.mail, 0, nmail * sizeof(double), st));
-    BK_HIP(hipMemsetAsync(s1.err, 0, sizeof(int), st));
+    if (mode != EIG_RESUME) {   // (a resumed decomposition keeps the watchdog word of its stage 1)
+      BK_HIP(hipMemsetAsync(s1.mail, 0, nmail * sizeof(double), st));
+      BK_HIP(hipMemsetAsync(s1.err, 0, sizeof(int), st));
+    }
     s1.Tall = q; q += ntall;
     s1.fpart = q; q += nfpart;
     taus1 = q; q += 2 * N;
@@ -2006,9 +2019,20 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     TT = VV + plan.nrefl * S2_B;
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
+    if (mode != EIG_RESUME) BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
+    if (mode == EIG_SETUP_ONLY) {
+      // the distributed stage 1 drives the panel steps itself (bigkrls_dev_s1_*): hand it the layout
+      if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
+      DistS1* ds = new DistS1();
+      ds->n = n;
+      ctx->dist_s1 = ds;
+      ctx->dist_s1_free = [](void* p) { delete (DistS1*)p; };
+      BK_TRY(ds->ops.init(ctx, W, n, taus1, s1));
+      BK_HIP(hipStreamSynchronize(st));   // plan.soff (host) was the source of an async copy
+      return BIGKRLS_OK;
+    }
     tick("setup + copy");
-    BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
+    if (mode == EIG_FULL) BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
     {
       // watchdog word of the register-resident panel QR: checked before stage 2 consumes the band
       int h_err1 = 0;
@@ -2017,6 +2041,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // BIGKRLS_FAULT=watchdog (tests): pretend the watchdog fired on the first attempt
       const char* fault = getenv("BIGKRLS_FAULT");
       if (fault && std::string(fault) == "watchdog" && !ctx->no_resident) h_err1 = 1;
+      if (h_err1 != 0 && mode == EIG_RESUME) {
+        set_error("eigen: watchdog of the register-resident panel QR fired during the distributed stage 1; "
+                  "rerun with BIGKRLS_PQ=steps");
+        return BIGKRLS_EHIP;
+      }
       if (h_err1 != 0) return eigen_retry_without_resident(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh,
                                                            vecs, ldv, h_n_vecs, part_index, part_count);
     }
@@ -2079,6 +2108,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
                          (const double*)VV, (const double*)TT, (const int64_t*)bt2_dtoff, bt2_T);
       BK_CHECK_LAUNCH();
       BK_HIP(hipEventRecord(ctx->ev_join, side));
+    }
+    if (h_err != 0 && mode == EIG_RESUME) {
+      set_error("eigen: watchdog of the LDS-resident bulge chasing fired; rerun with BIGKRLS_BC=wavefront");
+      return BIGKRLS_EHIP;
     }
     if (h_err != 0)
       return eigen_retry_without_resident(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv,
@@ -2148,6 +2181,73 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Row-block distributed stage 1 ("Eigen, dense"): the trailing matrix is
+// partitioned by column blocks over the ranks (K is symmetric: a column block is the row block
+// transposed); the reduced matrix W (band + reflectors), the panel QR and the thin products are
+// replicated -- deterministic kernels, bitwise identical on every rank. One panel step is
+//   [owner] strip = A[k:, k:k+b]  --broadcast-->  dist_s1_panel (QR, T factor)
+//   dist_s1_av: rows of Y = A22 V that belong to this rank's columns  --all-gather-->  Y
+//   dist_s1_update: Z from (V, Y, T), then A22[:, own columns] -= V Z[own,:]' + Z V[own,:]'
+// and after the last panel the remaining columns are broadcast into W (dist_s1_put) and every rank
+// calls eigen(..., EIG_RESUME) for stage 2, the divide & conquer and its slice of the back-transform.
+// ---------------------------------------------------------------------------
+static int dist_state(bigkrls_ctx* ctx, int64_t n, DistS1** out) {
+  DistS1* ds = (DistS1*)ctx->dist_s1;
+  if (!ds || ds->n != (int)n) {
+    set_error("distributed stage 1: call bigkrls_dev_s1_open(ctx, n) first");
+    return BIGKRLS_EINVAL;
+  }
+  *out = ds;
+  return BIGKRLS_OK;
+}
+
+int dist_s1_open(bigkrls_ctx* ctx, int64_t n) {
+  return eigen(ctx, nullptr, n, n, n, nullptr, 0, -1.0, nullptr, n, nullptr, 0, 1, EIG_SETUP_ONLY);
+}
+
+int dist_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_REQUIRE(strip && k >= 0 && k % S2_B == 0 && ds->ops.has_panel((int)k), "s1_panel: not a panel column");
+  double* W = ds->ops.W;
+  // rows k..n of the panel's columns: the final diagonal block and the sub-diagonal panel
+  BK_TRY(copy_matrix(ctx, strip, n - k, S2_B, n - k, W + k + k * n, n));
+  BK_TRY(ds->ops.panel_qr((int)k, ctx->stream));
+  BK_TRY(ds->ops.build_T((int)k, ctx->stream));
+  return BIGKRLS_OK;
+}
+
+int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda, int64_t ncols,
+               double* Yout, int64_t ldy) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  const int64_t m = n - k - S2_B;
+  BK_REQUIRE(m > 0 && ncols >= 0 && (ncols == 0 || (Acols && Yout && lda >= m && ldy >= ncols)), "s1_av: bad arguments");
+  if (ncols == 0) return BIGKRLS_OK;
+  // rows (own columns) of Y = A22 V: A22 is symmetric, so they are A22[:, own]' V
+  return gemm(ctx, 1, 0, ncols, S2_B, m, 1.0, Acols, lda, ds->ops.ws.Vp, m, 0.0, Yout, ldy);
+}
+
+int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
+                   int64_t row0) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  const int64_t m = n - k - S2_B;
+  BK_REQUIRE(Y && m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m, "s1_update: bad arguments");
+  BK_TRY(ds->ops.small_products((int)k, Y, nullptr));          // PZ1 = [V | Z], PZ2 = [Z | V]
+  if (ncols == 0) return BIGKRLS_OK;
+  BK_REQUIRE(Acols && lda >= m, "s1_update: bad column block");
+  return gemm(ctx, 0, 1, m, ncols, 2 * S2_B, -1.0, ds->ops.ws.PZ1, m, ds->ops.ws.PZ2 + row0, m, 1.0, Acols, lda);
+}
+
+int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_REQUIRE(strip && k >= 0 && ncols > 0 && k + ncols <= n, "s1_put: bad arguments");
+  return copy_matrix(ctx, strip, n - k, ncols, n - k, ds->ops.W + k + k * n, n);
 }
 
 }  // namespace bk

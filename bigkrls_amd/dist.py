@@ -46,9 +46,15 @@ def _host(backend, t):
     return t.contiguous().numpy()
 
 
-def partition(n: int, world: int):
-    """Equal blocks of nb = ceil(n/world) rows; the last ranks may be short or empty."""
+S1_B = 64          # panel width of the dense reduction (S2_B in csrc/eigen_2stage.inc)
+DENSE_DIST_MIN_N = 257   # below, the dense eigensolver stays replicated (one-stage path in the library)
+
+
+def partition(n: int, world: int, align: int = 1):
+    """Equal blocks of nb = ceil(n/world) rows, rounded up to a multiple of `align`; the last ranks
+    may be short or empty."""
     nb = (n + world - 1) // world
+    nb = (nb + align - 1) // align * align
     return nb, [(min(r * nb, n), min((r + 1) * nb, n)) for r in range(world)]
 
 
@@ -156,6 +162,43 @@ class HipBackend:
                   C.c_void_p(out.data_ptr()), out.shape[1])
         return out
 
+    # ---- dense eigensolver with stage 1 partitioned by column blocks -------------
+    def s1_open(self, n):
+        _lib.call("bigkrls_dev_s1_open", self.ctx.handle, n)
+
+    def s1_strip_from(self, A, lc, w, k, n, strip):
+        """strip ((w, n-k) tensor) = rows k..n of the local columns lc..lc+w of A ((ncl, n) tensor)."""
+        _lib.call("bigkrls_dev_copy_matrix", self.ctx.handle, C.c_void_p(A.data_ptr() + 8 * (lc * n + k)),
+                  n - k, w, n, C.c_void_p(strip.data_ptr()), n - k)
+
+    def s1_panel(self, n, k, strip):
+        _lib.call("bigkrls_dev_s1_panel", self.ctx.handle, n, k, C.c_void_p(strip.data_ptr()))
+
+    def s1_av(self, n, k, A, la0, ncols, Ysend):
+        """Rows la0.. of Ysend ((b, nb) tensor == nb x b column-major) = A22[:, own]' V."""
+        if ncols > 0:
+            _lib.call("bigkrls_dev_s1_av", self.ctx.handle, n, k,
+                      C.c_void_p(A.data_ptr() + 8 * (la0 * n + k + S1_B)), n, ncols,
+                      C.c_void_p(Ysend.data_ptr() + 8 * la0), Ysend.shape[1])
+
+    def s1_update(self, n, k, Y, A, la0, ncols, row0):
+        _lib.call("bigkrls_dev_s1_update", self.ctx.handle, n, k, C.c_void_p(Y.data_ptr()),
+                  C.c_void_p(A.data_ptr() + 8 * (la0 * n + k + S1_B)) if ncols > 0 else None, n, ncols, row0)
+
+    def s1_put(self, n, k, strip, ncols):
+        _lib.call("bigkrls_dev_s1_put", self.ctx.handle, n, k, C.c_void_p(strip.data_ptr()), ncols)
+
+    def eigen_resume(self, n, neig, eigtrunc, rank, world):
+        """Stage 2, divide & conquer and this rank's slice of the back-transform. Returns (values
+        host, lastkeeper, Q tensor (lastkeeper, n) whose rows outside the slice are zero, values tensor)."""
+        vals = self.ctx.empty(neig, 1)
+        vecs = self.ctx.empty(n, neig)
+        nv = C.c_int64(0)
+        _lib.call("bigkrls_dev_eigen_resume", self.ctx.handle, n, neig, vals.ptr, neig, float(eigtrunc), vecs.ptr, n,
+                  C.byref(nv), int(rank), int(world))
+        k = int(nv.value)
+        return vals.to_numpy().ravel(), k, vecs.t[:k], vals.t
+
     def dense_eig_top(self, T, k):
         """All eigenvalues (descending, host) and the top-k eigenvectors (tensor (k, m)) of the dense
         symmetric T given as a host array."""
@@ -232,7 +275,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         Wloc = torch.zeros((cols, nb), dtype=torch.float64, device=Bj.device)
         if r1 > r0:
             Wloc[:, : r1 - r0] = backend.mm(True, False, Kcols, Bj)     # (K[:, r0:r1])' Bj  = rows r0:r1 of K Bj
-        if world == 1:
+        if not dist.is_initialized():
             return Wloc[:, :n].contiguous()
         full = torch.empty((world * cols, nb), dtype=torch.float64, device=Bj.device)
         dist.all_gather_into_tensor(full, Wloc.contiguous())
@@ -253,7 +296,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
 
     def agree_min(values):
         """Element-wise minimum of a few host scalars over the ranks (control decisions only)."""
-        if world == 1:
+        if not dist.is_initialized():
             return [float(v) for v in values]
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=Kcols.device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -347,6 +390,79 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     return vals, lastkeeper, Qf, backend.from_numpy(vals[:, None])
 
 
+def eigen_dense_dist(backend, torch, dist, A, n, rank, world, nb, neig, eigtrunc):
+    """Dense symmetric eigendecomposition with stage 1 (dense -> band, 4/3 N^3 flops) partitioned by
+    column blocks over the ranks ("Eigen, dense tridiagonalisation").
+
+    `A`: this rank's column block K[:, c0:c1] as an (ncl, n) tensor, c0 = rank * nb, nb a multiple of
+    64; it is overwritten. Per 64-column panel: one broadcast of the panel strip from its owner, the
+    replicated panel QR, this rank's rows of Y = A22 V (A22 symmetric: its own columns, transposed),
+    one all-gather of Y (N x 64), the replicated thin products and the update of the own columns.
+    The reduced matrix (band + reflectors) ends up replicated; stage 2 and the divide & conquer are
+    replicated (latency-bound, no flops to share), the back-transform is split by eigenvector column
+    and assembled with an all-gather of the column blocks -- the RCCL exchange north_star names.
+    Returns (values host (neig), lastkeeper, Q tensor (lastkeeper, n), values tensor)."""
+    b = S1_B
+    assert nb % b == 0
+    c0 = min(rank * nb, n)
+    ncl = A.shape[0]
+    dev = A.device
+    backend.s1_open(n)
+    sbuf = torch.empty(b * n, dtype=torch.float64, device=dev)
+    Ysend = torch.zeros((b, nb), dtype=torch.float64, device=dev)
+    Yrecv = torch.empty((world * b, nb), dtype=torch.float64, device=dev) if dist.is_initialized() else None
+
+    def has_panel(k):
+        return k + b < n and n - k - b > 1
+
+    def bcast_strip(k, w):
+        """Rows k..n of the global columns k..k+w (inside one owner's block) on every rank."""
+        owner = k // nb
+        strip = sbuf[: w * (n - k)].view(w, n - k)
+        if owner == rank:
+            backend.s1_strip_from(A, k - c0, w, k, n, strip)
+        if dist.is_initialized():
+            dist.broadcast(strip, src=owner)
+        return strip
+
+    k = 0
+    while has_panel(k):
+        m = n - k - b
+        strip = bcast_strip(k, b)
+        backend.s1_panel(n, k, strip)
+        la0 = min(max(k + b - c0, 0), ncl)           # first own column inside the trailing matrix
+        nact = ncl - la0
+        backend.s1_av(n, k, A, la0, nact, Ysend)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(Yrecv, Ysend)
+            Yfull = Yrecv.view(world, b, nb).permute(1, 0, 2).reshape(b, world * nb)
+        else:
+            Yfull = Ysend
+        Y = Yfull[:, k + b: n].contiguous()          # m x 64, column-major
+        backend.s1_update(n, k, Y, A, la0, nact, (c0 + la0) - (k + b) if nact > 0 else 0)
+        k += b
+    while k < n:                                      # what is left of the trailing matrix: not panels
+        owner_end = min((k // nb + 1) * nb, n)
+        w = min(b, owner_end - k)
+        strip = bcast_strip(k, w)
+        backend.s1_put(n, k, strip, w)
+        k += w
+    vals, lastkeeper, Qpart, dvals = backend.eigen_resume(n, neig, eigtrunc, rank, world)
+    if not dist.is_initialized():
+        return vals, lastkeeper, Qpart, dvals
+    # all-gather of the back-transformed column blocks (rank r holds columns nv r / world .. nv (r+1) / world)
+    cuts = [lastkeeper * r // world for r in range(world + 1)]
+    pmax = max(cuts[r + 1] - cuts[r] for r in range(world))
+    send = torch.zeros((pmax, n), dtype=torch.float64, device=dev)
+    mine = cuts[rank + 1] - cuts[rank]
+    if mine > 0:
+        send[:mine] = Qpart[cuts[rank]: cuts[rank + 1]]
+    recv = torch.empty((world * pmax, n), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    Q = torch.cat([recv[r * pmax: r * pmax + (cuts[r + 1] - cuts[r])] for r in range(world)], dim=0).contiguous()
+    return vals, lastkeeper, Q, dvals
+
+
 def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig=None, eigtrunc=None,
                  lambda_=None, L=None, U=None, ctx: Optional[Context] = None, backend=None,
                  timings: Optional[Dict[str, float]] = None, trace=None, keep_outputs=True,
@@ -356,10 +472,14 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     Every rank returns the same small outputs; N x N outputs stay sharded
     (`K.cols`, `vcov.est.c.cols`, `vcov.est.fitted.cols` hold this rank's column block).
     `eigen_mode`: None (block Lanczos with sharded products when N >= 16384 and Neig <= N/8, like
-    the single-GPU library), "krylov" or "dense" to force either."""
+    the single-GPU library; otherwise the dense path with stage 1 partitioned by column blocks),
+    "krylov" / "dense" to force either, "replicated" for the dense decomposition replicated on every
+    rank (K all-gathered; what tiny problems, n <= 256, always use)."""
     import torch
     import torch.distributed as dist
 
+    # (every collective below runs whenever a process group exists, also one of size 1: a
+    #  single-GPU run under an RCCL group then exercises exactly the calls of a multi-GPU one)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if backend is None:
@@ -379,7 +499,12 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     y_init_sd, y_init_mean = _sd(yh), float(yh.mean())
     Xs = (Xh - Xh.mean(axis=0)) / X_init_sd
     ys = (yh - y_init_mean) / y_init_sd
-    nb, parts = partition(n, world)
+    Neig_eff = min(int(Neig), n)
+    use_krylov = (eigen_mode == "krylov") or (eigen_mode is None and Neig_eff * 8 <= n and n >= 16384)
+    # dense: stage 1 partitioned by column blocks (64-column panels must not straddle two ranks);
+    # tiny problems (and eigen_mode="replicated") keep the replicated decomposition
+    dense_sharded = not use_krylov and eigen_mode != "replicated" and n >= DENSE_DIST_MIN_N
+    nb, parts = partition(n, world, S1_B if dense_sharded else 1)
     r0, r1 = parts[rank]
     T = timings if timings is not None else {}
     t_last = [time.perf_counter()]
@@ -394,14 +519,25 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     Xd = backend.from_numpy(Xs)
     yd = backend.from_numpy(ys)
     # ---- step 1: kernel, column blocks + all-gather -------------------------------
-    Kpad = backend.empty(n, nb * world)          # (nb*world, n): column c at Kpad[c]
-    Kloc = Kpad[rank * nb: rank * nb + (r1 - r0)]
+    if dense_sharded or use_krylov:
+        Kpad = None                              # K stays sharded: only the own column block exists
+        Kloc = backend.empty(n, r1 - r0)
+    else:
+        Kpad = backend.empty(n, nb * world)      # (nb*world, n): column c at Kpad[c]
+        Kloc = Kpad[rank * nb: rank * nb + (r1 - r0)]
     if r1 > r0:
         backend.kernel_cols(Xd, sigma, r0, r1, Kloc)
     mark("kernel")
-    Neig_eff = n if Neig is None else min(int(Neig), n)
-    use_krylov = (eigen_mode == "krylov") or (eigen_mode is None and Neig_eff * 8 <= n and n >= 16384)
-    if use_krylov:
+    if dense_sharded:
+        # K is never gathered: every rank keeps (and later reuses) only its own column block, and the
+        # reduction works on a copy of it
+        Kcols = Kloc
+        mark("kernel_allgather")
+        vals, lastkeeper, Q, dvals = eigen_dense_dist(backend, torch, dist, Kloc.clone(), n, rank, world, nb,
+                                                       Neig_eff, eigtrunc)
+        K = None
+        mark("eigen")
+    elif use_krylov:
         # Neig << N: K stays sharded (no all-gather of K); block Lanczos with sharded K B_j products
         Kcols = Kloc
         mark("kernel_allgather")
@@ -410,26 +546,26 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
         K = None
         mark("eigen")
     else:
-        if world > 1:
+        if dist.is_initialized():
             dist.all_gather_into_tensor(Kpad, Kpad[rank * nb:(rank + 1) * nb].clone())
         K = Kpad[:n]
         Kcols = K[r0:r1]
         mark("kernel_allgather")
         # ---- step 2: eigen (replicated) -------------------------------------------------
         vals, lastkeeper, Q, dvals = backend.eigen(K, Neig, eigtrunc, rank, world)
-        if world > 1:
+        if dist.is_initialized():
             # each rank back-transformed its own eigenvector columns (zeros elsewhere): sum = Q.
             # This is the RCCL exchange north_star names for the eigenvector back-transform.
             dist.all_reduce(Q, op=dist.ReduceOp.SUM)
         mark("eigen")
     # ---- step 3: lambda search on row blocks of Q ------------------------------------
     a = backend.qty_rows(Q, r0, r1, yd)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(a)
 
     def loo(lam):
         le, _ = backend.solveforc_rows(Q, r0, r1, dvals, a, lam, False)
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([le], dtype=torch.float64, device=a.device)
             dist.all_reduce(t)
             le = float(t.item())
@@ -444,7 +580,7 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     mark("lambda")
     # ---- step 4: coefficients, fitted values, variances -------------------------------
     le_loc, c_loc = backend.solveforc_rows(Q, r0, r1, dvals, a, lambda_, True)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([le_loc], dtype=torch.float64, device=a.device)
         dist.all_reduce(t)
         Le = float(t.item())
@@ -452,7 +588,7 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     else:
         Le, c_full = le_loc, c_loc
     yhat_loc = backend.gemv_t(Kcols, c_full)
-    yhat_full = _all_gather_vec(torch, dist, yhat_loc, nb, n, world) if world > 1 else yhat_loc
+    yhat_full = _all_gather_vec(torch, dist, yhat_loc, nb, n, world) if dist.is_initialized() else yhat_loc
     coeffs = _host(backend, c_full).ravel()
     yfitted = _host(backend, yhat_full).ravel()
     mark("coeffs")
@@ -470,7 +606,7 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
         Xe = Xd if which_derivatives is None else backend.from_numpy(Xe_h)
         isb = ops.binary_columns(Xe_h)
         D_loc, S_loc = backend.deriv_rows(Kcols, r0, Xe, isb, c_full, sigma)
-        if world > 1:
+        if dist.is_initialized():
             D_full = _all_gather_vec(torch, dist, D_loc, nb, n, world)
             S_full = _all_gather_vec(torch, dist, S_loc, nb, n, world)
         else:

@@ -34,8 +34,10 @@
  * be called concurrently. bigkrls_last_error() is per thread.
  * The eigensolver's persistent kernels spin on messages from other workgroups;
  * they are launched with grids no larger than the co-resident capacity of the
- * device and every wait is bounded: a violated assumption surfaces as BIGKRLS_EHIP
- * (message names the fallback switches BIGKRLS_BC / BIGKRLS_PQ), never as a hang.
+ * device and every wait is bounded: when a watchdog fires (the workgroups were not
+ * co-resident, e.g. another process held part of the GPU) the decomposition is
+ * redone in the same call with one launch per step -- never a hang, and an error
+ * (BIGKRLS_EHIP) only from the distributed stage 1, which cannot be replayed.
  */
 #ifndef BIGKRLS_H
 #define BIGKRLS_H
@@ -188,6 +190,36 @@ int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t
                            int64_t n_vals, double* vals,
                            int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
                            int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
+
+/* ---- dense eigensolver with stage 1 partitioned over the GPUs of a node ---------------------------
+ * ("Eigen, dense tridiagonalisation"; one process per GPU, the caller owns the
+ * collectives -- torch.distributed / RCCL in bigkrls_amd/dist.py). Rank r holds the column block
+ * A[:, c0:c1) of the symmetric matrix (column-major, ld n; the block is overwritten), c0 and c1
+ * multiples of 64. Per 64-column panel k = 0, 64, ... while k + 64 < n - 1:
+ *   1. the owner of columns [k, k+64) broadcasts strip = A[k:n, k:k+64) ((n-k) x 64, ld n-k);
+ *   2. every rank: bigkrls_dev_s1_panel (replicated Householder QR of the sub-diagonal panel, T factor);
+ *   3. every rank: bigkrls_dev_s1_av on its columns >= k+64: Yout (ncols x 64) = A22[:, own]' V, the rows
+ *      of Y = A22 V that belong to them; all-gather -> Y (m x 64, m = n-k-64, contiguous);
+ *   4. every rank: bigkrls_dev_s1_update(Y): Z from (V, Y, T) and A22[:, own] -= V Z[own,:]' + Z V[own,:]'
+ *      (Acols points at row k+64 of the first own column >= k+64; row0 = that column's index - (k+64)).
+ * After the last panel the owners broadcast the remaining columns A[k:n, k:n) and every rank stores them
+ * with bigkrls_dev_s1_put. bigkrls_dev_eigen_resume then runs stage 2, the divide & conquer and the
+ * back-transform of this rank's slice of the kept eigenvector columns (same contract as
+ * bigkrls_dev_eigen_part; the caller all-gathers the column blocks). Between s1_open and eigen_resume
+ * no other decomposition may run on the context. n must exceed 256. */
+int bigkrls_dev_s1_open(bigkrls_ctx* ctx, int64_t n);
+int bigkrls_dev_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
+int bigkrls_dev_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda,
+                      int64_t ncols, double* Yout, int64_t ldy);
+int bigkrls_dev_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda,
+                          int64_t ncols, int64_t row0);
+int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
+int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals,
+                             int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
+                             int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
+/* dst (m x n, ldd) = src (m x n, lds), both on the device */
+int bigkrls_dev_copy_matrix(bigkrls_ctx* ctx, const double* src, int64_t m, int64_t n, int64_t lds,
+                            double* dst, int64_t ldd);
 
 /* a = Q'y (k-vector), hoisted out of the lambda probes. Q rows [0,n), ld ldq. */
 int bigkrls_dev_qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,

@@ -58,6 +58,82 @@ class NumpyBackend:
             V[c1:] = 0.0
         return eo.values, eo.lastkeeper, torch.from_numpy(V), torch.from_numpy(eo.values.copy())[None, :]
 
+    # ---- test double of the per-panel stage-1 entry points (bigkrls_dev_s1_*) and eigen_resume ----
+    def s1_open(self, n):
+        self._n = n
+        self._W = np.zeros((n, n))
+        self._V, self._T = {}, {}
+
+    def s1_strip_from(self, A, lc, w, k, n, strip):
+        strip.copy_(A[lc:lc + w, k:n])
+
+    def s1_panel(self, n, k, strip):
+        import scipy.linalg as sla
+        b = bkdist.S1_B
+        W = self._W
+        W[k:, k:k + b] = strip.numpy().T
+        P = W[k + b:, k:k + b]
+        (qr, tau), _ = sla.qr(P, mode="raw")
+        m = P.shape[0]
+        ncol = min(b, m)
+        V = np.tril(qr, -1)[:, :b]
+        V[np.arange(ncol), np.arange(ncol)] = 1.0
+        V[:, ncol:] = 0.0
+        tau = np.concatenate([tau, np.zeros(b - tau.size)])
+        T = np.zeros((b, b))                     # dlarft, forward columnwise
+        for j in range(b):
+            T[j, j] = tau[j]
+            if j > 0:
+                T[:j, j] = -tau[j] * (T[:j, :j] @ (V[:, :j].T @ V[:, j]))
+        W[k + b:, k:k + b] = np.triu(qr)[:, :b] if m >= b else qr
+        if m >= b:
+            W[k + 2 * b:, k:k + b] = V[b:, :]
+            W[k + b:k + 2 * b, k:k + b] = np.triu(qr[:b, :b]) + np.tril(V[:b, :b], -1)
+        self._V[k], self._T[k] = V, T
+
+    def s1_av(self, n, k, A, la0, ncols, Ysend):
+        if ncols > 0:
+            b = bkdist.S1_B
+            Acols = A.numpy()[la0:la0 + ncols, k + b:n]            # (ncols, m): own columns, transposed
+            Ysend[:, la0:la0 + ncols] = torch.from_numpy((Acols @ self._V[k]).T.copy())
+
+    def s1_update(self, n, k, Y, A, la0, ncols, row0):
+        b = bkdist.S1_B
+        V, T = self._V[k], self._T[k]
+        Yt = Y.numpy().T @ T
+        S = T.T @ (V.T @ Yt)
+        Z = Yt - 0.5 * V @ S
+        if ncols > 0:
+            An = A.numpy()
+            An[la0:la0 + ncols, k + b:n] -= (V @ Z[row0:row0 + ncols].T + Z @ V[row0:row0 + ncols].T).T
+
+    def s1_put(self, n, k, strip, ncols):
+        self._W[k:, k:k + ncols] = strip.numpy().T
+
+    def eigen_resume(self, n, neig, eigtrunc, rank, world):
+        """Eigenpairs of the band matrix (LAPACK) back-transformed with the stored block reflectors;
+        only this rank's slice of the kept columns, zeros elsewhere (the contract of the library)."""
+        b = bkdist.S1_B
+        W = self._W
+        B = np.zeros((n, n))
+        for d in range(b + 1):
+            idx = np.arange(n - d)
+            B[idx + d, idx] = W[idx + d, idx]
+            B[idx, idx + d] = W[idx + d, idx]
+        w, Z = np.linalg.eigh(B)
+        w, Z = w[::-1][:neig].copy(), Z[:, ::-1][:, :neig].copy()
+        for k in sorted(self._V, reverse=True):                     # Q = Q_0 Q_1 ... Q_last
+            V, T = self._V[k], self._T[k]
+            Z[k + b:] -= V @ (T @ (V.T @ Z[k + b:]))
+        keep = np.nonzero(w >= eigtrunc * w[0])[0]
+        nv = int(keep.max()) + 1
+        Q = np.ascontiguousarray(Z[:, :nv].T)
+        if world > 1:
+            c0, c1 = nv * rank // world, nv * (rank + 1) // world
+            Q[:c0] = 0.0
+            Q[c1:] = 0.0
+        return w, nv, torch.from_numpy(Q), torch.from_numpy(w.copy())[None, :]
+
     def qty_rows(self, Q, r0, r1, y):
         return torch.from_numpy((Q.numpy()[:, r0:r1] @ y.numpy().ravel()[r0:r1])[None, :].copy())
 
@@ -152,9 +228,41 @@ def main_krylov():
     dist.destroy_process_group()
 
 
+def main_dense():
+    """eigen_dense_dist (stage 1 partitioned by column blocks: broadcast of the panel strip, all-gather of
+    A22 V per panel, all-gather of the eigenvector column blocks) against LAPACK on the full K."""
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, p, neig = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    X, y = orc.synth(n, p, 79)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    be = NumpyBackend()
+    nb, parts = bkdist.partition(n, world, bkdist.S1_B)
+    r0, r1 = parts[rank]
+    Kcols = be.empty(n, r1 - r0)
+    if r1 > r0:
+        be.kernel_cols(be.from_numpy(Xs), float(p), r0, r1, Kcols)
+    vals, lastkeeper, Q, dvals = bkdist.eigen_dense_dist(be, torch, dist, Kcols.clone(), n, rank, world, nb, neig, 0.001)
+    K = orc.gauss_kernel_literal(Xs, float(p))
+    w, V = np.linalg.eigh(K)
+    w = w[::-1]
+    assert vals.shape == (neig,)
+    assert np.max(np.abs(vals - w[:neig])) <= 1e-12 * w[0], (rank, np.max(np.abs(vals - w[:neig])) / w[0])
+    assert lastkeeper == int(np.max(np.nonzero(w[:neig] >= 0.001 * w[0])[0])) + 1
+    Qn = Q.numpy().T
+    assert Qn.shape == (n, lastkeeper)
+    assert np.max(np.abs(Qn.T @ Qn - np.eye(lastkeeper))) < 1e-11
+    assert np.max(np.abs(K @ Qn - Qn * vals[:lastkeeper])) <= 1e-11 * w[0]
+    print("OK", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if sys.argv[1] == "krylov":
         return main_krylov()
+    if sys.argv[1] == "dense":
+        return main_dense()
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     n, p = int(sys.argv[1]), int(sys.argv[2])
@@ -167,6 +275,9 @@ def main():
         be._Kfull = K.numpy().T.copy()
         return orig_eigen(K, neig, eigtrunc, rank, world)
     be.eigen = eigen_capture
+    # (the sharded eigensolvers never gather K: give the derivative double its full K directly)
+    Xs_ = (X - X.mean(0)) / X.std(0, ddof=1)
+    be._Kfull = orc.gauss_kernel_literal(Xs_, float(p))
     tr = []
     out = bkdist.bigKRLS_dist(y, X, backend=be, trace=tr)
     ref_tr = orc.LambdaTrace(0, 0)
@@ -184,7 +295,7 @@ def main():
     for k in ["R2", "R2AME", "Looe", "Neffective", "sigmasq"]:
         assert abs(out[k] - ref[k]) <= 1e-9 * abs(ref[k]), (rank, k)
     r0, r1 = out["rows"]
-    nb, parts = bkdist.partition(n, world)
+    nb, parts = bkdist.partition(n, world, bkdist.S1_B if n >= bkdist.DENSE_DIST_MIN_N else 1)
     assert (r0, r1) == parts[rank]
     assert rel(out["K.cols"].numpy().T, ref["K"][:, r0:r1]) < 1e-12
     assert rel(out["vcov.est.c.cols"].numpy().T, ref["vcov.est.c"][:, r0:r1]) < 1e-9

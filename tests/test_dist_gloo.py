@@ -42,3 +42,32 @@ def test_sharded_block_lanczos_matches_lapack(world, n, p, neig):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("OK") == world
+
+
+@pytest.mark.parametrize("world,n,p,neig", [(2, 300, 3, 300), (3, 333, 2, 333), (2, 275, 3, 40), (1, 290, 3, 290)])
+def test_sharded_dense_eigen_matches_lapack(world, n, p, neig):
+    """SURVEY 8(e) "Eigen, dense tridiagonalisation": stage 1 partitioned by column blocks -- per
+    64-column panel one broadcast of the panel strip and one all-gather of A22 V; the reduced matrix is
+    replicated, the back-transformed eigenvector columns are all-gathered. n not a multiple of 64 (ragged
+    last block, empty last rank at world 3), Neig = N and Neig < N."""
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "_dist_worker.py"), "dense", str(n), str(p), str(neig)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == world
+
+
+def test_row_block_fit_with_sharded_dense_eigen_matches_oracle():
+    """The whole row-block fit at a size that takes the sharded dense eigensolver (n > 256): K is never
+    gathered, Q arrives by an all-gather of column blocks."""
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "_dist_worker.py"), "280", "8", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == 2

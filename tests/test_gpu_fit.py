@@ -324,3 +324,64 @@ def test_crossvalidate_fold_parallel_contexts(ctx):
         assert two[k] == seq[k], k                      # deterministic kernels: bitwise the same on any context
     c0 = two["fold_1"]["trained"]["_ctx"]
     assert two["fold_3"]["trained"]["_ctx"] is c0 and two["fold_2"]["trained"]["_ctx"] is not c0
+
+
+@pytest.mark.gpu
+def test_dist_dense_sharded_eigen_world1_hip_backend(ctx):
+    """The dense eigensolver with stage 1 driven panel by panel through bigkrls_dev_s1_* (the
+    multi-GPU code path of bigkrls_amd.dist, SURVEY 8(e) "Eigen, dense"), HIP backend, one GPU, no
+    process group: eigenpairs against the single-call library, the fit against bigKRLS()."""
+    import torch
+    import bigkrls_amd as bk
+    from bigkrls_amd import dist as bkdist, ops
+    n, p = 1500, 6
+    X, y = orc.synth(n, p, 53)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    be = bkdist.HipBackend(ctx)
+    nb, parts = bkdist.partition(n, 1, bkdist.S1_B)
+    for neig, trunc in ((n, 0.001), (100, -1.0)):
+        vals, nv, Q, _ = bkdist.eigen_dense_dist(be, torch, torch.distributed, K.t.clone(), n, 0, 1, nb, neig, trunc)
+        ref = ops.bEigen(K, neig, trunc)
+        assert nv == ref.lastkeeper and rel(vals, ref.values) < 1e-12
+        Qd = bk.device.DeviceMatrix(ctx, Q.contiguous())
+        R = ops.gemm(False, False, K, Qd).to_numpy() - Qd.to_numpy() * vals[:nv]
+        G = ops.gemm(True, False, Qd, Qd).to_numpy()
+        assert np.abs(R).max() / vals[0] < 1e-11 and np.abs(G - np.eye(nv)).max() < 1e-11
+    one = bk.bigKRLS(y, X, ctx=ctx)
+    out = bkdist.bigKRLS_dist(y, X, ctx=ctx)
+    assert out["lastkeeper"] == one["lastkeeper"] and abs(out["lambda"] - one["lambda"]) <= 1e-9 * one["lambda"]
+    for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives", "K.eigenvalues"):
+        assert rel(out[k], one[k]) < 1e-8, k
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_dist_paths_under_a_world1_rccl_group(ctx):
+    """`nccl` (== RCCL) process group of size 1 on the GPU: every collective of the row-block fit --
+    broadcast of the panel strips, all-gather of A22 V, all-gather of the eigenvector column blocks,
+    all-gather of the Lanczos blocks, the all-reduces of the lambda search -- is issued through RCCL
+    (dist.py runs them whenever a group exists). Dense-sharded and block-Lanczos eigen paths."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import bigkrls_amd as bk
+    from bigkrls_amd import dist as bkdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                            device_id=torch.device("cuda", ctx.device_index))
+    try:
+        X, y = orc.synth(900, 5, 54, binary_last=True)
+        ref = orc.fit(y, X, literal=False)
+        out = bkdist.bigKRLS_dist(y, X, ctx=ctx)                          # dense, stage 1 by column blocks
+        assert_fit_parity(out, ref, squares=False)
+        X2, y2 = orc.synth(4500, 6, 52)
+        one = bk.bigKRLS(y2, X2, Neig=96, ctx=ctx)
+        kr = bkdist.bigKRLS_dist(y2, X2, Neig=96, ctx=ctx, eigen_mode="krylov")
+        assert kr["lastkeeper"] == one["lastkeeper"] and abs(kr["lambda"] - one["lambda"]) <= 1e-8 * one["lambda"]
+        assert rel(kr["coeffs"], one["coeffs"]) < TOL and rel(kr["derivatives"], one["derivatives"]) < TOL
+        rp = bkdist.bigKRLS_dist(y, X, ctx=ctx, eigen_mode="replicated")   # K all-gathered, Q by all-reduce
+        assert_fit_parity(rp, ref, squares=False)
+    finally:
+        dist.destroy_process_group()
