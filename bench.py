@@ -290,8 +290,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     sec_per_fit = dt / args.steps
 
     prof = {name: ctx.get_profile(name) for name in
-            ("symv", "kernel_block", "trailing_update", "band_update", "band_av", "bulge_chase", "panel_qr",
-             "lanczos_kb", "lanczos_cgs2")}
+            ("symv", "kernel_block", "trailing_update", "band_update", "band_update2", "band_av", "bulge_chase",
+             "panel_qr", "lanczos_kb", "lanczos_cgs2")}
     ctx.set_profile(False)
 
     res = None
@@ -391,6 +391,15 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "HBM bytes of the launch (read 4 m^2 + write 8 m^2) x the FETCH_SIZE+WRITE_SIZE / algorithmic "
                        "ratio of profiles/r01_traffic_pmc.json (1.011)",
                        traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel"), 0))
+                       if pmc_ratio("syrk_mirror_kernel") else None),
+            mfma_entry("band_update2", "syrk_mirror_kernel<64> at k = 256: A22 -= [V Z V Z][Z V Z V]' for a GROUP of two "
+                       "panels, applied as two pieces of equal area (the columns right / left of a cut), one per panel "
+                       "step, each concurrent with the next panel's QR (stage 1 while the trailing matrix has >= 12288 rows)",
+                       "achieved = algorithmic flops of the piece's columns of the lower triangle, 2*256*sum_c (m - c), / "
+                       "HIP-event duration on the launch stream; traffic = algorithmic HBM bytes of the piece (read 4 + write 8 "
+                       "bytes per lower-triangle entry, mirrored: 12 bytes per 256 flops) x the FETCH_SIZE+WRITE_SIZE / "
+                       "algorithmic ratio measured for this kernel (profiles/r01_traffic_pmc.json, 1.011)",
+                       traffic=(lambda flops: round(12.0 * flops / 256.0 * pmc_ratio("syrk_mirror_kernel"), 0))
                        if pmc_ratio("syrk_mirror_kernel") else None),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
                        "achieved = 2 m^2 b flops per launch / HIP-event duration"),

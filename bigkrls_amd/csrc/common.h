@@ -114,6 +114,7 @@ enum Slot {
   SLOT_FIT_Q = 32,         // ... eigenvectors (n x Neig)
   SLOT_FIT_M = 33,         // ... Q diag(w) / K_new V
   SLOT_FIT_K = 34,         // ... the kernel when the caller does not want it back
+  SLOT_EIG_AGG = 35,       // stage 1: reflector blocks of the panel groups whose trailing update is pending
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
@@ -138,6 +139,9 @@ int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doubl
 int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                 const double* B, int64_t ldb, double* C, int64_t ldc, int tn_begin = 0,
                 int tn_end = -1, bool narrow_tiles = false, bool skip_first_column = false);
+// the same update restricted to the 64-wide columns [c64_begin, c64_end) (128 x 64 tiles)
+int syrk_mirror_cols(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double* C, int64_t ldc, int c64_begin, int c64_end);
 int side_stream_get(bigkrls_ctx* ctx);
 // raise a kernel's dynamic shared-memory limit once per context (device)
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes);

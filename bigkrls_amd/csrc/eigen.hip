@@ -2020,6 +2020,16 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
     if (mode != EIG_RESUME) BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
+    if (mode == EIG_FULL && n >= 14848 + 4 * S2_B) {
+      // reflector blocks of the two panel groups whose trailing update is pending (stage1_to_band)
+      void* pagg = nullptr;
+      const int64_t blk = N * 4 * S2_B;
+      BK_TRY(ws_get(ctx, SLOT_EIG_AGG, (4 * blk + 3 * 4 * S2_B * S2_B) * (int64_t)sizeof(double), &pagg));
+      double* qa = (double*)pagg;
+      s1.aggPZ1[0] = qa; s1.aggPZ2[0] = qa + blk; s1.aggPZ1[1] = qa + 2 * blk; s1.aggPZ2[1] = qa + 3 * blk;
+      s1.aggC = qa + 4 * blk;
+      s1.aggLd = N;
+    }
     if (mode == EIG_SETUP_ONLY) {
       // the distributed stage 1 drives the panel steps itself (bigkrls_dev_s1_*): hand it the layout
       if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);

@@ -706,6 +706,35 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
   return launch_syrk_mirror<128>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
 }
 
+// 128 x 64 tiles, columns [c64_begin, c64_end) in units of 64: the lower triangle (with the
+// diagonal) of exactly those columns is updated and mirrored. Tiles are ordered by 128-wide column
+// group, inside a group first all tiles of its first 64-wide column, then those of the second.
+int syrk_mirror_cols(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double* C, int64_t ldc, int c64_begin, int c64_end) {
+  if (m <= 0 || k <= 0) return BIGKRLS_OK;
+  BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror_cols: dimension too large");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
+  const int tiles = (int)((m + BM - 1) / BM);
+  const int ncol64 = (int)((m + 63) / 64);
+  if (c64_end < 0 || c64_end > ncol64) c64_end = ncol64;
+  if (c64_begin < 0) c64_begin = 0;
+  if (c64_begin >= c64_end) return BIGKRLS_OK;
+  auto tile_index = [&](int c64) -> int64_t {     // index of the first tile of 64-wide column c64
+    const int64_t q = c64 / 2;
+    if (q >= tiles) return 2 * ((int64_t)tiles * tiles - (int64_t)tiles * (tiles - 1) / 2);
+    return 2 * (q * tiles - q * (q - 1) / 2) + ((c64 & 1) ? tiles - q : 0);
+  };
+  // (an odd last column of the matrix: the second column of the last group does not exist, but its
+  //  tiles are enumerated; they lie entirely outside the matrix and store nothing)
+  const int64_t t0 = tile_index(c64_begin), nt = tile_index(c64_end == ncol64 ? 2 * tiles : c64_end) - t0;
+  if (nt <= 0) return BIGKRLS_OK;
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<64>, smem_bytes(64)));
+  hipLaunchKernelGGL(syrk_mirror_kernel<64>, dim3((unsigned)nt), dim3(NT), smem_bytes(64), ctx->stream, g,
+                     alpha, C, ldc, tiles, (int)t0);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                const double* B, int64_t ldb, double* C, int64_t ldc) {
   if (m <= 0 || k <= 0) return BIGKRLS_OK;

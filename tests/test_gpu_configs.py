@@ -347,3 +347,25 @@ def test_eigen_watchdog_retry_and_lanczos_fallback(ctx, monkeypatch):
     assert rel(fb.values, kr.values) < 1e-10
     res, orth = eigen_quality(ops, K2, fb.vectors, fb.values)
     assert res < 1e-11 and orth < 1e-11
+
+
+def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatch):
+    """Stage 1 above 14848 trailing rows applies the trailing update for two panels at once (k = 256),
+    as two pieces of equal area with thin corrections of everything that reads the stale matrix
+    (csrc/eigen_2stage.inc, "aggregated phase"). n = 15700 runs a few groups of it plus the hand-over to
+    one update per panel; BIGKRLS_S1AGG=0 is the plain loop. Same eigenvalues to rounding, kept
+    eigenvectors with residual and orthogonality at rounding level."""
+    from bigkrls_amd import ops
+    from bigkrls_amd.synth import synth
+    n, p = 15700, 7
+    X, _ = synth(n, p, 91)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    monkeypatch.setenv("BIGKRLS_S1AGG", "0")
+    plain = ops.bEigen(K, None, 0.001)
+    monkeypatch.delenv("BIGKRLS_S1AGG")
+    agg = ops.bEigen(K, None, 0.001)
+    assert agg.lastkeeper == plain.lastkeeper
+    assert rel(agg.values, plain.values) < 1e-13
+    res, orth = eigen_quality(ops, K, agg.vectors, agg.values)
+    assert res < 1e-11 and orth < 1e-11 and abs(agg.values.sum() - n) < 1e-11 * n
