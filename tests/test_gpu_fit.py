@@ -385,3 +385,36 @@ def test_dist_paths_under_a_world1_rccl_group(ctx):
         assert_fit_parity(rp, ref, squares=False)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_contexts_fit_concurrently_on_one_gpu():
+    """Two contexts with their own streams on one device, one host thread each, fitting at the same
+    time (include/bigkrls.h "Threading": one context per thread). n = 5000: the persistent kernels of
+    both decompositions (24 + 79 workgroups each) are co-resident. Results must be bitwise those of the
+    same fits run one after the other."""
+    import threading
+    import bigkrls_amd as bk
+    data = [orc.synth(5000, 6, 60 + i) for i in range(2)]
+    ctxs = [bk.Context(0, own_stream=True) for _ in range(2)]
+    seq = [bk.bigKRLS(y, X, ctx=c) for (X, y), c in zip(data, ctxs)]
+    par = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            ctxs[i].torch.cuda.set_device(0)
+            par[i] = bk.bigKRLS(data[i][1], data[i][0], ctx=ctxs[i])
+        except BaseException as e:          # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for s, p in zip(seq, par):
+        assert p["lambda"] == s["lambda"] and p["lastkeeper"] == s["lastkeeper"]
+        for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives", "K.eigenvalues"):
+            assert np.array_equal(p[k], s[k]), k
