@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=900.0,
                     help="wall-clock bound of the CPU baseline; what is measured until then is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="route a single-GPU run through the row-block path (bigkrls_amd.dist) under an RCCL group "
+                         "of size 1: exercises exactly the code of --gpus N > 1 on one GPU")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     custom = False
@@ -212,8 +215,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -240,7 +244,7 @@ def main():
                            f"{8e-9 * cfg['n'] ** 2:.0f} GB matrix, hours; SURVEY.md section 8(d)); pass --cpu-n to time "
                            "the restatement on a smaller sample of the same generator")}
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 
@@ -253,7 +257,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     X, y = synth(n, p, cfg["seed"])
     fit_kw = dict(Neig=cfg["neig"], eigtrunc=cfg["eigtrunc"], which_derivatives=cfg["which"])
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         from bigkrls_amd import dist as bkdist
 
         def one_fit(timings):
@@ -441,7 +445,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "name": cfg["name"], "n": n, "p": p, "seed": cfg["seed"], "neig": cfg["neig"],
                        "which_derivatives": cfg["which"], "lastkeeper": int(lastkeeper),
                        "lambda": float(lam),
-                       "parallelism": "1 GPU" if world == 1 else f"row-block x{world}, RCCL all-gather"},
+                       "parallelism": ("1 GPU" if world == 1 and not args.force_dist
+                                       else f"row-block x{world}, RCCL broadcast / all-gather")},
             "phases_s": phases,
             "kernel_gemm": {
                 "gflops": round(kb_flops / (kb_ms / 1e3) / 1e9, 1) if kb_ms > 0 else None,
