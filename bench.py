@@ -243,7 +243,14 @@ def main():
                 "sample": (f"not timed at N={cfg['n']}: the literal CPU path is infeasible at this size (dsyevd of a "
                            f"{8e-9 * cfg['n'] ** 2:.0f} GB matrix, hours; SURVEY.md section 8(d)); pass --cpu-n to time "
                            "the restatement on a smaller sample of the same generator")}
-        print(json.dumps(res))
+        # RCCL writes a version banner to the C-level stdout, which is flushed at exit: flush it now so
+        # that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
