@@ -101,13 +101,19 @@ def symv_traffic(alg_bytes_total, launches):
 
 
 def pmc_ratio(kernel):
-    """traffic / algorithmic HBM bytes of a kernel from the rocprofv3 PMC passes in
-    profiles/r01_traffic_pmc.json (FETCH_SIZE + WRITE_SIZE, separate passes, calibrated there)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
-    try:
-        return float(json.load(open(path))[kernel]["traffic_over_algorithmic"])
-    except Exception:
-        return None
+    """traffic / algorithmic HBM bytes of a kernel from the rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 correction and calibration as described in the files):
+    profiles/r02/r02_traffic_pmc.json (the kernels of the current stage 1, keys matched by prefix),
+    else profiles/r01_traffic_pmc.json."""
+    for rel in (("profiles", "r02", "r02_traffic_pmc.json"), ("profiles", "r01_traffic_pmc.json")):
+        try:
+            d = json.load(open(os.path.join(ROOT, *rel)))
+        except Exception:
+            continue
+        for key, val in d.items():
+            if key.startswith(kernel) and isinstance(val, dict) and "traffic_over_algorithmic" in val:
+                return float(val["traffic_over_algorithmic"])
+    return None
 
 
 class CpuBaseline:
@@ -400,20 +406,26 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "b = 64, m = trailing size minus the next panel's 64 columns, which the preceding fused "
                        "kernel s1_fused_z updates) / HIP-event duration on the launch stream; traffic = algorithmic "
                        "HBM bytes of the launch (read 4 m^2 + write 8 m^2) x the FETCH_SIZE+WRITE_SIZE / algorithmic "
-                       "ratio of profiles/r01_traffic_pmc.json (1.011)",
-                       traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel"), 0))
-                       if pmc_ratio("syrk_mirror_kernel") else None),
+                       "ratio of profiles/r02/r02_traffic_pmc.json for the 128x64-tile variant (1.149)",
+                       traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel<64> k=128"), 0))
+                       if pmc_ratio("syrk_mirror_kernel<64> k=128") else None),
             mfma_entry("band_update2", "syrk_mirror_kernel<64> at k = 256: A22 -= [V Z V Z][Z V Z V]' for a GROUP of two "
                        "panels, applied as two pieces of equal area (the columns right / left of a cut), one per panel "
                        "step, each concurrent with the next panel's QR (stage 1 while the trailing matrix has >= 12288 rows)",
                        "achieved = algorithmic flops of the piece's columns of the lower triangle, 2*256*sum_c (m - c), / "
                        "HIP-event duration on the launch stream; traffic = algorithmic HBM bytes of the piece (read 4 + write 8 "
                        "bytes per lower-triangle entry, mirrored: 12 bytes per 256 flops) x the FETCH_SIZE+WRITE_SIZE / "
-                       "algorithmic ratio measured for this kernel (profiles/r01_traffic_pmc.json, 1.011)",
-                       traffic=(lambda flops: round(12.0 * flops / 256.0 * pmc_ratio("syrk_mirror_kernel"), 0))
-                       if pmc_ratio("syrk_mirror_kernel") else None),
+                       "algorithmic ratio measured for the two pieces (profiles/r02/r02_traffic_pmc.json, 1.194)",
+                       traffic=(lambda flops: round(12.0 * flops / 256.0 * pmc_ratio("syrk_mirror_kernel<64> k=256, the two"), 0))
+                       if pmc_ratio("syrk_mirror_kernel<64> k=256, the two") else None),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
-                       "achieved = 2 m^2 b flops per launch / HIP-event duration"),
+                       "achieved = 2 m^2 b flops per launch (b = 64) / HIP-event duration; traffic = algorithmic HBM bytes of "
+                       "the launch (A22 read once, 8 m^2, + V and Y, 16 m b: 1/16 byte per flop) x the ratio of "
+                       "profiles/r02/r02_traffic_pmc.json (1.07: FETCH_SIZE doubled per the gfx950 correction for its "
+                       "16-B-per-lane operand loads, + WRITE_SIZE, + the split-K reduction)",
+                       traffic=(lambda flops: round((flops / 16.0 + 16.0 * (flops / 128.0) ** 0.5 * 64.0)
+                                                    * pmc_ratio("gemm_kernel<N,N,64>"), 0))
+                       if pmc_ratio("gemm_kernel<N,N,64>") else None),
             mfma_entry("lanczos_kb", "gemm_kernel<N,N,128>: W = K B_j, the N x N x 128 product of one block-Lanczos "
                        "step (Neig << N, the reference's eigs_sym branch src/eigen.cpp:18-22)",
                        "achieved = 2 N^2 b flops (b = 128) per step / HIP-event duration on the launch stream, every "
