@@ -65,13 +65,22 @@ def _as_host_matrix(X) -> np.ndarray:
 
 def _call_native(name, *args):
     """A library call whose BIGKRLS_EINVAL (the reference's validation errors, with R's message
-    text) becomes the ValueError the R-mirroring API raises; everything else stays a BigKRLSError."""
-    try:
-        _lib.call(name, *args)
-    except _lib.BigKRLSError as e:
-        if e.code == _lib.EINVAL:
-            raise ValueError(str(e).split(": ", 2)[-1]) from None
-        raise
+    text) becomes the ValueError the R-mirroring API raises; BIGKRLS_ENOMEM is retried once after
+    torch's cached-but-unused device blocks were released; everything else stays a BigKRLSError."""
+    for attempt in (0, 1):
+        try:
+            _lib.call(name, *args)
+            return
+        except _lib.BigKRLSError as e:
+            if e.code == _lib.EINVAL:
+                raise ValueError(str(e).split(": ", 2)[-1]) from None
+            if e.code == _lib.ENOMEM and attempt == 0:
+                # the library's workspace comes from hipMalloc; blocks that torch's caching allocator
+                # holds but does not use are invisible to it: hand them back to the driver and retry once
+                import torch
+                torch.cuda.empty_cache()
+                continue
+            raise
 
 
 def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None, vcov_est=True,

@@ -30,6 +30,7 @@
 #include <string>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 
 namespace bk {
 namespace {
@@ -1638,64 +1639,108 @@ __global__ void kry_fill_random(double* __restrict__ p, int64_t total, unsigned 
   }
 }
 
-// host: upper Cholesky factor R (G = R'R, column-major b x b) and Rinv = R^{-1}; false on breakdown
-bool kry_chol_inv(const std::vector<double>& G, int b, std::vector<double>& R, std::vector<double>& Rinv) {
-  R.assign((size_t)b * b, 0.0);
-  for (int j = 0; j < b; ++j) {
-    for (int i = 0; i <= j; ++i) {
-      double s = G[i + (size_t)j * b];
-      for (int k = 0; k < i; ++k) s -= R[k + (size_t)i * b] * R[k + (size_t)j * b];
-      if (i < j) R[i + (size_t)j * b] = s / R[i + (size_t)i * b];
-      else {
-        if (!(s > 0.0) || !std::isfinite(s)) return false;
-        R[j + (size_t)j * b] = std::sqrt(s);
-      }
-    }
+// One workgroup: upper Cholesky factor R (G = R'R) and its inverse of a b x b SPD matrix (b <= 128),
+// in LDS and in place. G (column-major, ld b) is symmetrised first; R goes to Rout (zero below the
+// diagonal), inv(R) overwrites G. *flag is set when a pivot is not positive (breakdown).
+constexpr int KRY_B = 128;
+__global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ G, int b, double* __restrict__ Rout,
+                                                            int* __restrict__ flag) {
+  __shared__ double A[KRY_B][KRY_B + 1];   // A[i][j], i <= j: R; i > j: inv(R)[j][i] (strictly upper part, transposed)
+  const int tid = threadIdx.x;
+  for (int e = tid; e < b * b; e += 256) {
+    const int i = e % b, j = e / b;
+    A[i][j] = 0.5 * (G[i + (int64_t)j * b] + G[j + (int64_t)i * b]);
   }
-  Rinv.assign((size_t)b * b, 0.0);
-  for (int j = 0; j < b; ++j) {          // solve R x = e_j (upper triangular) column by column
-    Rinv[j + (size_t)j * b] = 1.0 / R[j + (size_t)j * b];
+  __syncthreads();
+  for (int k = 0; k < b; ++k) {
+    const double d = A[k][k];
+    if (!(d > 0.0) || !isfinite(d)) {   // uniform
+      if (tid == 0) *flag = 1;
+      return;
+    }
+    const double r = sqrt(d);
+    __syncthreads();                    // everybody has read the pivot
+    for (int j = k + tid; j < b; j += 256) A[k][j] = (j == k) ? r : A[k][j] / r;
+    __syncthreads();
+    const int nt = b - k - 1;
+    for (int e = tid; e < nt * nt; e += 256) {
+      const int i = k + 1 + e / nt, j = k + 1 + e % nt;
+      if (j >= i) A[i][j] -= A[k][i] * A[k][j];
+    }
+    __syncthreads();
+  }
+  // inv(R): column j by back substitution, one thread per column; X[i][j] (i < j) is kept at A[j][i]
+  if (tid < b) {
+    const int j = tid;
+    const double xjj = 1.0 / A[j][j];
     for (int i = j - 1; i >= 0; --i) {
-      double s = 0.0;
-      for (int k = i + 1; k <= j; ++k) s += R[i + (size_t)k * b] * Rinv[k + (size_t)j * b];
-      Rinv[i + (size_t)j * b] = -s / R[i + (size_t)i * b];
+      double s = A[i][j] * xjj;
+      for (int kk = i + 1; kk < j; ++kk) s += A[i][kk] * A[j][kk];
+      A[j][i] = -s / A[i][i];
     }
   }
-  return true;
+  __syncthreads();
+  for (int e = tid; e < b * b; e += 256) {
+    const int i = e % b, j = e / b;
+    Rout[i + (int64_t)j * b] = (i <= j) ? A[i][j] : 0.0;
+    G[i + (int64_t)j * b] = (i < j) ? A[j][i] : ((i == j) ? 1.0 / A[i][i] : 0.0);
+  }
 }
 
-// W (n x b, ld n) <- orthonormal basis of its columns by Cholesky QR; Rout (host, b x b upper) gets
-// the triangular factor with W_in = W_out Rout. tmp is an n x b scratch. Returns 1 on breakdown.
+// The projected block-tridiagonal matrix T (m x m, m = steps * b) from the blocks kept on the device:
+// diagonal blocks sym(A_j), sub-diagonal blocks beta_{j+1} (upper triangular) and their transposes.
+__global__ void kry_assemble_t(const double* __restrict__ Aall, const double* __restrict__ Ball, int steps, int b,
+                               double* __restrict__ T) {
+  const int64_t m = (int64_t)steps * b, total = m * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e % m, c = e / m;
+    const int jr = (int)(r / b), jc = (int)(c / b), lr = (int)(r % b), lc = (int)(c % b);
+    double v = 0.0;
+    if (jr == jc) {
+      const double* Aj = Aall + (int64_t)jr * b * b;
+      v = 0.5 * (Aj[lr + (int64_t)lc * b] + Aj[lc + (int64_t)lr * b]);
+    } else if (jr == jc + 1) {          // T[j+1, j] = beta_{j+1}
+      if (lr <= lc) v = Ball[(int64_t)jc * b * b + lr + (int64_t)lc * b];
+    } else if (jc == jr + 1) {          // T[j, j+1] = beta_{j+1}'
+      if (lc <= lr) v = Ball[(int64_t)jr * b * b + lc + (int64_t)lr * b];
+    }
+    T[e] = v;
+  }
+}
+
+// W (n x b, ld n) <- orthonormal basis of its columns by Cholesky QR, twice; Rout (host, b x b upper)
+// gets the triangular factor with W_in = W_out Rout. tmp is an n x b scratch, dG holds 4 b^2 doubles
+// and an int. Everything runs on the device (Gram matrix, factorisation and inverse in one workgroup,
+// W R^-1 as a GEMM); one synchronisation at the end brings Rout and the breakdown flag to the host.
 int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, double* dG,
-               std::vector<double>& Rout, bool* breakdown) {
+               std::vector<double>& Rout, bool* breakdown, double* dRkeep = nullptr) {
   hipStream_t st = ctx->stream;
-  std::vector<double> G((size_t)b * b), R, Rinv, Racc;
+  BK_REQUIRE(b <= KRY_B, "kry_cholqr: block too wide");
+  double* dR1 = dG + (int64_t)b * b;
+  double* dR2 = dR1 + (int64_t)b * b;
+  double* dRacc = dR2 + (int64_t)b * b;
+  int* dflag = (int*)(dRacc + (int64_t)b * b);
   *breakdown = false;
+  BK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
   for (int pass = 0; pass < 2; ++pass) {
     BK_TRY(gemm(ctx, 1, 0, b, b, n, 1.0, *W, n, *W, n, 0.0, dG, b));
-    BK_HIP(hipMemcpyAsync(G.data(), dG, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
-    BK_HIP(hipStreamSynchronize(st));
-    for (int j = 0; j < b; ++j)
-      for (int i = 0; i < j; ++i) {      // exact symmetry for the host factorisation
-        const double v = 0.5 * (G[i + (size_t)j * b] + G[j + (size_t)i * b]);
-        G[i + (size_t)j * b] = v;
-        G[j + (size_t)i * b] = v;
-      }
-    if (!kry_chol_inv(G, b, R, Rinv)) { *breakdown = true; return BIGKRLS_OK; }
-    BK_HIP(hipMemcpyAsync(dG, Rinv.data(), (size_t)b * b * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kry_chol_inv_kernel, dim3(1), dim3(256), 0, st, dG, b, pass == 0 ? dR1 : dR2, dflag);
+    BK_CHECK_LAUNCH();
     BK_TRY(gemm(ctx, 0, 0, n, b, b, 1.0, *W, n, dG, b, 0.0, *tmp, n));
-    BK_HIP(hipStreamSynchronize(st));    // Rinv (host) was the source of an async copy
     std::swap(*W, *tmp);
-    if (pass == 0) Racc = R;
-    else {                               // Rout = R2 * R1
-      Rout.assign((size_t)b * b, 0.0);
-      for (int j = 0; j < b; ++j)
-        for (int k = 0; k <= j; ++k) {
-          const double r1 = Racc[k + (size_t)j * b];
-          for (int i = 0; i <= k; ++i) Rout[i + (size_t)j * b] += R[i + (size_t)k * b] * r1;
-        }
-    }
   }
+  BK_TRY(gemm(ctx, 0, 0, b, b, b, 1.0, dR2, b, dR1, b, 0.0, dRacc, b));   // Rout = R2 R1
+  if (dRkeep) BK_HIP(hipMemcpyAsync(dRkeep, dRacc, (size_t)b * b * sizeof(double), hipMemcpyDeviceToDevice, st));
+  // R2 R1 and the flag (they sit next to each other on the device) come down in one copy through the
+  // context's pinned buffer
+  double* hp = nullptr;
+  BK_TRY(pinned_get(ctx, (int64_t)b * b + 8, &hp));
+  BK_HIP(hipMemcpyAsync(hp, dRacc, ((size_t)b * b + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+  BK_HIP(hipStreamSynchronize(st));
+  Rout.assign(hp, hp + (size_t)b * b);
+  int h_flag = 0;
+  std::memcpy(&h_flag, hp + (size_t)b * b, sizeof(int));
+  if (h_flag != 0) *breakdown = true;   // (W then holds garbage; the caller stops with the blocks it has)
   return BIGKRLS_OK;
 }
 
@@ -1705,26 +1750,32 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
           int part_index, int part_count, int mode);
 
+static thread_local std::string kry_diag;   // what the last block Lanczos did at its convergence checks (for the error text)
+
 static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t k, double* vals,
                         int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
                         int64_t* h_n_vecs, int part_index, int part_count) {
   hipStream_t st = ctx->stream;
   constexpr int b = 128;
   const double tol = 1e-10;
+  kry_diag.clear();
   const int64_t maxdim = std::min<int64_t>(n / 2 / b * b, std::max<int64_t>(16 * k, 4096) / b * b);
   const int maxsteps = (int)(maxdim / b);
   void *pB = nullptr, *pW = nullptr, *pC = nullptr;
   BK_TRY(ws_get(ctx, SLOT_KRY_B, n * maxdim * sizeof(double), &pB));
   BK_TRY(ws_get(ctx, SLOT_KRY_W, 2 * n * (int64_t)std::max<int64_t>(b, k) * sizeof(double), &pW));
-  BK_TRY(ws_get(ctx, SLOT_KRY_C, (maxdim * b + 2 * b * b + k * k + 2 * k) * sizeof(double), &pC));
+  BK_TRY(ws_get(ctx, SLOT_KRY_C, (maxdim * b + 5 * b * b + 8 + k * k + 2 * k + 2 * (int64_t)maxsteps * b * b) *
+                                     sizeof(double), &pC));
   double* B = (double*)pB;
   double* W = (double*)pW;
   double* W2 = W + n * std::max<int64_t>(b, k);
   double* C = (double*)pC;
-  double* dG = C + maxdim * b;
-  double* dA = dG + b * b;
-  std::vector<std::vector<double>> Ablk, Bblk;     // diagonal blocks A_j and sub-diagonal factors beta_{j+1}
-  std::vector<double> Rtmp, hA((size_t)b * b);
+  double* dG = C + maxdim * b;            // Cholesky-QR scratch: Gram / inverse, R1, R2, R2 R1, flag
+  double* dA = dG + 4 * b * b + 8;
+  // diagonal blocks A_j and sub-diagonal factors beta_{j+1} of the projected matrix stay on the device
+  double* dAall = dA + b * b + k * k + 2 * k;
+  double* dBall = dAall + (int64_t)maxsteps * b * b;
+  std::vector<double> Rtmp;                        // beta of the last step (host copy, for the Ritz residuals)
   bool breakdown = false;
   // ---- B_0 ----------------------------------------------------------------------------------
   hipLaunchKernelGGL(kry_fill_random, dim3(2048), dim3(256), 0, st, W, n * b, 20240229u);
@@ -1750,57 +1801,44 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_cgs2", 8.0 * (double)n * (double)dim * b));
     for (int pass = 0; pass < 2; ++pass) {
       BK_TRY(gemm(ctx, 1, 0, dim, b, n, 1.0, B, n, W, n, 0.0, C, dim));
-      if (pass == 0)
-        BK_HIP(hipMemcpy2DAsync(dA, b * sizeof(double), C + (int64_t)steps * b, dim * sizeof(double),
-                                b * sizeof(double), b, hipMemcpyDeviceToDevice, st));
+      if (pass == 0)   // A_j = B_j' K B_j: rows [steps b, steps b + b) of the first coefficient block
+        BK_TRY(copy_matrix(ctx, C + (int64_t)steps * b, b, b, dim, dAall + (int64_t)steps * b * b, b));
       BK_TRY(gemm(ctx, 0, 0, n, b, dim, -1.0, B, n, C, dim, 1.0, W, n));
     }
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_cgs2"));
-    BK_HIP(hipMemcpyAsync(hA.data(), dA, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
-    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown));   // synchronises the stream
-    for (int j = 0; j < b; ++j)
-      for (int i = 0; i < j; ++i) {
-        const double v = 0.5 * (hA[i + (size_t)j * b] + hA[j + (size_t)i * b]);
-        hA[i + (size_t)j * b] = v;
-        hA[j + (size_t)i * b] = v;
-      }
-    Ablk.push_back(hA);
+    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b));   // synchronises the stream
     ++steps;
     const bool last = breakdown || steps >= maxsteps;
-    if (!breakdown) Bblk.push_back(Rtmp);
     // ---- convergence check on the projected problem ---------------------------------------------
     if (last || steps >= next_check) {
       const int64_t m = (int64_t)steps * b;
-      std::vector<double> T((size_t)m * m, 0.0);
-      for (int j = 0; j < steps; ++j) {
-        for (int c = 0; c < b; ++c)
-          for (int r = 0; r < b; ++r) T[(j * b + r) + (size_t)(j * b + c) * m] = Ablk[j][r + (size_t)c * b];
-        if (j + 1 < steps)
-          for (int c = 0; c < b; ++c)
-            for (int r = 0; r <= c; ++r) {          // beta_{j+1} upper triangular: T[j+1, j] = beta, T[j, j+1] = beta'
-              const double v = Bblk[j][r + (size_t)c * b];
-              T[((j + 1) * b + r) + (size_t)(j * b + c) * m] = v;
-              T[(j * b + c) + (size_t)((j + 1) * b + r) * m] = v;
-            }
-      }
       void *pT = nullptr;
       BK_TRY(ws_get(ctx, SLOT_KRY_T, (m * m + m) * sizeof(double), &pT));
       BK_TRY(ws_get(ctx, SLOT_KRY_Y, m * k * sizeof(double), &pY));
       double* dT = (double*)pT;
       double* dvalsT = dT + m * m;
-      BK_HIP(hipMemcpyAsync(dT, T.data(), (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipStreamSynchronize(st));
+      hipLaunchKernelGGL(kry_assemble_t, dim3((unsigned)std::min<int64_t>((m * m + 255) / 256, 8192)), dim3(256), 0, st,
+                         (const double*)dAall, (const double*)dBall, steps, b, dT);
+      BK_CHECK_LAUNCH();
       int64_t nvY = 0;
       BK_TRY(eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1, EIG_FULL));
+      // theta (m values) and the last b rows of Y come down through the context's pinned buffer
+      double* hp = nullptr;
+      BK_TRY(pinned_get(ctx, m + (int64_t)b * k, &hp));
       theta.resize(m);
-      BK_HIP(hipMemcpy(theta.data(), dvalsT, m * sizeof(double), hipMemcpyDeviceToHost));
       double worst = 0.0;
+      std::vector<double> Ylast((size_t)b * k);
+      {
+        BK_HIP(hipMemcpyAsync(hp, dvalsT, m * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipMemcpy2DAsync(hp + m, b * sizeof(double), (double*)pY + (m - b), m * sizeof(double),
+                                b * sizeof(double), k, hipMemcpyDeviceToHost, st));
+        BK_HIP(hipStreamSynchronize(st));
+        std::memcpy(theta.data(), hp, (size_t)m * sizeof(double));
+        std::memcpy(Ylast.data(), hp + m, (size_t)b * k * sizeof(double));
+      }
       if (!breakdown) {
         // residual of Ritz pair i: | beta_m * y_i[last block] |
-        std::vector<double> Ylast((size_t)b * k);
-        BK_HIP(hipMemcpy2D(Ylast.data(), b * sizeof(double), (double*)pY + (m - b), m * sizeof(double),
-                           b * sizeof(double), k, hipMemcpyDeviceToHost));
-        const std::vector<double>& beta = Bblk.back();
+        const std::vector<double>& beta = Rtmp;
         for (int64_t i = 0; i < k; ++i) {
           double r2 = 0.0;
           for (int r = 0; r < b; ++r) {
@@ -1810,6 +1848,11 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
           }
           worst = std::max(worst, std::sqrt(r2));
         }
+      }
+      {
+        char buf[160];
+        snprintf(buf, sizeof buf, " [check steps=%d worst=%.3e theta0=%.6e breakdown=%d]", steps, worst, theta[0], (int)breakdown);
+        kry_diag += buf;
       }
       if (worst <= tol * std::fabs(theta[0]) || last) {
         converged = worst <= tol * std::fabs(theta[0]);
@@ -1841,7 +1884,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     return BIGKRLS_ENOCONV;
   }
   if (!converged) {
-    set_error("eigen (Krylov): not converged within the subspace limit; use the dense path (BIGKRLS_EIGK=dense)");
+    set_error("eigen (Krylov): not converged within the subspace limit; use the dense path (BIGKRLS_EIGK=dense);" + kry_diag);
     return BIGKRLS_ENOCONV;
   }
   // ---- Ritz vectors Q = B Y and one Rayleigh-Ritz refinement against K itself --------------------
@@ -1933,7 +1976,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // handed to the dense path in the same call -- A is untouched. Only an explicit
       // BIGKRLS_EIGK=krylov reports the non-convergence.
       if (rc != BIGKRLS_ENOCONV || mode == "krylov") return rc;
-      if (getenv("BIGKRLS_VERBOSE")) fprintf(stderr, "[bigkrls] block Lanczos did not converge: dense path\n");
+      if (getenv("BIGKRLS_VERBOSE"))
+        fprintf(stderr, "[bigkrls] block Lanczos did not converge: dense path;%s\n", kry_diag.c_str());
     }
   }
   const int n = (int)n64;

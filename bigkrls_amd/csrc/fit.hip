@@ -210,7 +210,8 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
     dK = (double*)pk;
   }
   double* pin = nullptr;
-  BK_TRY(pinned_get(ctx, std::max<int64_t>(n * std::max<int64_t>(p, pd) + n, 2 * neig + 64), &pin));
+  const int64_t pin_doubles = std::max<int64_t>(n * std::max<int64_t>(p, pd) + n, 2 * neig + 64);
+  BK_TRY(pinned_get(ctx, pin_doubles, &pin));
 
   PhaseTimer timer(ctx);
   timer.mark();
@@ -235,6 +236,7 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   // ---- step 2: eigen (:266-269; bEigen's lastkeeper rule on the device side) ------------------------
   int64_t lastkeeper = 0;
   BK_TRY(eigen(ctx, dK, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper));
+  BK_TRY(pinned_get(ctx, pin_doubles, &pin));   // (the eigensolver may have grown -- and so moved -- the pinned buffer)
   std::vector<double> vals(neig);
   BK_TRY(download(ctx, vals.data(), dvals, neig, pin));
   for (int64_t i = 0; i < neig; ++i)
