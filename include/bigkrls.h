@@ -74,10 +74,13 @@ void* bigkrls_ctx_stream(bigkrls_ctx* ctx);
 int64_t bigkrls_ctx_workspace_bytes(bigkrls_ctx* ctx);
 int bigkrls_ctx_release_workspace(bigkrls_ctx* ctx);
 
-/* HIP-event sampling of the dominant kernels on the context's stream (used by
- * bench.py for the roofline figures; off by default). Names: "kernel_block" (work =
- * flops 2*u*v*p), "symv" (work = bytes of the lower triangle streamed), 
- * "trailing_update" (work = flops). */
+/* HIP-event sampling of the dominant kernels on their launch streams (used by
+ * bench.py for the roofline figures; off by default). Names and their `work`:
+ * "kernel_block" (flops 2*u*v*p), "band_av" (A22 V of a stage-1 panel, flops),
+ * "band_update" / "band_update2" (trailing update per panel at k = 128 / the pieces
+ * of the two-panel update at k = 256, flops), "panel_qr" and "bulge_chase"
+ * (algorithmic bytes), "lanczos_kb" / "lanczos_cgs2" (block-Lanczos step, flops),
+ * "symv" (one-stage path, bytes of the lower triangle streamed). */
 int bigkrls_ctx_set_profile(bigkrls_ctx* ctx, int enable);
 int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms,
                             double* total_work, int64_t* launches);
