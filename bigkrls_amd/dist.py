@@ -50,6 +50,14 @@ S1_B = 64          # panel width of the dense reduction (S2_B in csrc/eigen_2sta
 DENSE_DIST_MIN_N = 257   # below, the dense eigensolver stays replicated (one-stage path in the library)
 
 
+def _torch_dist():
+    """(torch, torch.distributed) as bigKRLS_dist uses them. tools/dist_world2_one_gpu.py replaces this
+    with an object that stages device tensors through the host, to drive WORLD_SIZE > 1 on one GPU."""
+    import torch
+    import torch.distributed as dist
+    return torch, dist
+
+
 def partition(n: int, world: int, align: int = 1):
     """Equal blocks of nb = ceil(n/world) rows, rounded up to a multiple of `align`; the last ranks
     may be short or empty."""
@@ -475,8 +483,7 @@ def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig
     the single-GPU library; otherwise the dense path with stage 1 partitioned by column blocks),
     "krylov" / "dense" to force either, "replicated" for the dense decomposition replicated on every
     rank (K all-gathered; what tiny problems, n <= 256, always use)."""
-    import torch
-    import torch.distributed as dist
+    torch, dist = _torch_dist()
 
     # (every collective below runs whenever a process group exists, also one of size 1: a
     #  single-GPU run under an RCCL group then exercises exactly the calls of a multi-GPU one)

@@ -12,6 +12,48 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# Multi-rank runs of the HIP backend on one GPU (tests/_dist_world_gpu.py): N, P, WORLD, extra arguments.
+WORLD_CASES = {
+    "dense_world2": ["3000", "8", "2"],
+    "dense_world3_ragged": ["2500", "6", "3"],
+    "krylov_world2": ["17000", "10", "2", "--krylov", "60"],
+}
+_world_runs = {}
+
+
+def pytest_sessionstart(session):
+    """The rank processes have to be started before this process initialises the GPU (a process that holds
+    the GPU must not start other programs on this pool), i.e. here, not inside a test. Counting devices does
+    not initialise anything."""
+    expr = session.config.getoption("markexpr", "") or ""
+    if "not gpu" in expr or os.environ.get("BIGKRLS_SKIP_WORLD_RUNS"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() == 0:
+            return
+    except Exception:
+        return
+    import subprocess
+    import tempfile
+    for name, args in WORLD_CASES.items():
+        log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_world_gpu.py")] + args,
+                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+        _world_runs[name] = (proc, log.name)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for proc, _ in _world_runs.values():
+        if proc.poll() is None:
+            proc.kill()
+
+
+@pytest.fixture(scope="session")
+def world_runs():
+    return _world_runs
+
+
 @pytest.fixture(scope="session")
 def lib():
     """ctypes handle of libbigkrls_hip.so; the GPU tests call through this C ABI."""
