@@ -142,6 +142,10 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
 // the same update restricted to the 64-wide columns [c64_begin, c64_end) (128 x 64 tiles)
 int syrk_mirror_cols(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, int c64_begin, int c64_end);
+// C = alpha A B' where the product is symmetric (A = Q diag(w), B = Q): half the MFMA work of the GEMM, exactly
+// symmetric result
+int syrk_mirror_set(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc);
 int side_stream_get(bigkrls_ctx* ctx);
 // raise a kernel's dynamic shared-memory limit once per context (device)
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes);

@@ -294,7 +294,7 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
-        BK_TRY(gemm(ctx, 0, 1, n, n, k, sd2, dM, n, dQ, n, 0.0, out->d_vcov_c, n));
+        BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_c, n));
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_c
@@ -304,7 +304,7 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         for (int64_t i = 0; i < k; ++i) pin[i] = wv[i] * vals[i] * vals[i];
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
-        BK_TRY(gemm(ctx, 0, 1, n, n, k, sd2, dM, n, dQ, n, 0.0, out->d_vcov_fitted, n));
+        BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_fitted, n));
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_fitted

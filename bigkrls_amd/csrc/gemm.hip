@@ -560,7 +560,8 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_lower_kernel(GemmOperands g
 // triangle (through a per-wave 16 x 16 LDS transpose so that the mirrored stores are 128-byte
 // segments too): C stays a fully stored, exactly symmetric matrix at half the MFMA work of a
 // full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
-template <int BN>
+// ACCUM = false: C = alpha A B' (nothing of C is read): the N x N variance matrices Q diag(w) Q' of the fit.
+template <int BN, bool ACCUM = true>
 __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_kernel(
     GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, int tiles, int t_off) {
   // Tiles are 128 x BN. BN = 64 halves the accumulators so that THREE workgroups fit a CU: the
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cold[i][r] = cb[i * 16 + (int64_t)(j * 16 + 4 * r) * ldc];
+        for (int r = 0; r < 4; ++r) cold[i][r] = ACCUM ? cb[i * 16 + (int64_t)(j * 16 + 4 * r) * ldc] : 0.0;
     };
     d4 cbuf[2][4];
     load_int(0, cbuf[0]);
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn + j * 16 + lk + 4 * r;
-        cold[i][r] = (m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
+        cold[i][r] = (ACCUM && m < M && n < M && m >= n) ? C[(int64_t)m + (int64_t)n * ldc] : 0.0;
       }
     }
   };
@@ -704,6 +705,21 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
   BK_REQUIRE(!skip_first_column || narrow_tiles, "syrk_mirror: skip_first_column needs 64-wide tiles");
   if (narrow_tiles) return launch_syrk_mirror<64>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end, skip_first_column);
   return launch_syrk_mirror<128>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
+}
+
+// C = alpha A B' for a product that is symmetric (A = Q diag(w), B = Q): lower tiles computed, stored twice
+int syrk_mirror_set(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc) {
+  if (m <= 0) return BIGKRLS_OK;
+  BK_REQUIRE(k > 0 && m < (1ll << 31) && k < (1ll << 31), "syrk_mirror_set: bad dimensions");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
+  const int tiles = (int)((m + BM - 1) / BM);
+  const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<128, false>, smem_bytes(128)));
+  hipLaunchKernelGGL((syrk_mirror_kernel<128, false>), dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
+                     alpha, C, ldc, tiles, 0);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
 }
 
 // 128 x 64 tiles, columns [c64_begin, c64_end) in units of 64: the lower triangle (with the
