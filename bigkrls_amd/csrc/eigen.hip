@@ -1639,6 +1639,26 @@ __global__ void kry_fill_random(double* __restrict__ p, int64_t total, unsigned 
   }
 }
 
+// out[c] = || KQ[:, c] - theta[c] Q[:, c] ||^2, one workgroup per column (the true residual of a Ritz pair)
+__global__ __launch_bounds__(256) void kry_resid_sq_kernel(const double* __restrict__ KQ, const double* __restrict__ Q,
+                                                            const double* __restrict__ theta, int64_t n,
+                                                            double* __restrict__ out) {
+  __shared__ double part[4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double th = theta[c];
+  const double* kq = KQ + (int64_t)c * n;
+  const double* q = Q + (int64_t)c * n;
+  double acc = 0.0;
+  for (int64_t i = tid; i < n; i += 256) {
+    const double r = kq[i] - th * q[i];
+    acc += r * r;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((tid & 63) == 0) part[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) out[c] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // One workgroup: upper Cholesky factor R (G = R'R) and its inverse of a b x b SPD matrix (b <= 128),
 // in LDS and in place. G (column-major, ld b) is symmetrised first; R goes to Rout (zero below the
 // diagonal), inv(R) overwrites G. *flag is set when a pivot is not positive (breakdown).
@@ -1897,21 +1917,57 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     set_error("eigen (Krylov): not converged within the subspace limit; use the dense path (BIGKRLS_EIGK=dense);" + kry_diag);
     return BIGKRLS_ENOCONV;
   }
-  // ---- Ritz vectors Q = B Y and one Rayleigh-Ritz refinement against K itself --------------------
+  // ---- Ritz vectors Q = B Y -------------------------------------------------------------------------
+  // With full re-orthogonalisation the Ritz pairs of T are Ritz pairs of K and |beta y_last| is their residual.
+  // That is verified against K itself on the block of pairs that converge last (the smallest min(k, 128) Ritz
+  // values: one more K-times-block product); only if the true residuals are not at the estimated level are
+  // all k pairs refined by a Rayleigh-Ritz step against K (k more columns of K Q and a k x k eigenproblem),
+  // which is what every call did before (BIGKRLS_KRY_REFINE=1 still forces it).
   double* Q = W;                        // n x k (W, W2 are n x max(b,k))
   double* KQ = W2;
   BK_TRY(gemm(ctx, 0, 0, n, k, dim, 1.0, B, n, (double*)pY, dim, 0.0, Q, n));
-  BK_TRY(gemm(ctx, 0, 0, n, k, n, 1.0, A, lda, Q, n, 0.0, KQ, n));
   double* dH = dA + b * b;              // k x k + 2k
   double* dvalsH = dH + k * k;
-  BK_TRY(gemm(ctx, 1, 0, k, k, n, 1.0, Q, n, KQ, n, 0.0, dH, k));
+  std::vector<double> hv(theta.begin(), theta.begin() + k);     // Ritz values of T, descending
+  bool refine = false;
+  {
+    const char* rf = getenv("BIGKRLS_KRY_REFINE");
+    refine = rf && std::string(rf) == "1";
+  }
+  const double* dvals_final = nullptr;
+  if (!refine) {
+    const int64_t bs = std::min<int64_t>(k, b), c0 = k - bs;
+    // theta of T sits at the head of SLOT_KRY_T's value vector (device): dvalsT of the last check
+    void* pT = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_KRY_T, (dim * dim + dim) * sizeof(double), &pT));
+    const double* dtheta = (const double*)pT + dim * dim;
+    BK_TRY(gemm(ctx, 0, 0, n, bs, n, 1.0, A, lda, Q + c0 * n, n, 0.0, KQ, n));
+    hipLaunchKernelGGL(kry_resid_sq_kernel, dim3((unsigned)bs), dim3(256), 0, st, (const double*)KQ,
+                       (const double*)(Q + c0 * n), dtheta + c0, n, dvalsH);
+    BK_CHECK_LAUNCH();
+    double* hp = nullptr;
+    BK_TRY(pinned_get(ctx, bs, &hp));
+    BK_HIP(hipMemcpyAsync(hp, dvalsH, bs * sizeof(double), hipMemcpyDeviceToHost, st));
+    BK_HIP(hipStreamSynchronize(st));
+    double rmax = 0.0;
+    for (int64_t i = 0; i < bs; ++i) rmax = std::max(rmax, std::sqrt(std::max(hp[i], 0.0)));
+    if (getenv("BIGKRLS_VERBOSE"))
+      fprintf(stderr, "[bigkrls] block Lanczos: true residual of the last %lld pairs %.3e (tolerance %.3e)\n", (long long)bs,
+              rmax, tol * std::fabs(theta[0]));
+    if (!(rmax <= 10.0 * tol * std::fabs(theta[0]))) refine = true;    // also NaN
+    dvals_final = dtheta;
+  }
   void* pZ = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
-  int64_t nvZ = 0;
-  BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1, EIG_FULL));
-  std::vector<double> hv(k);
-  BK_HIP(hipMemcpy(hv.data(), dvalsH, k * sizeof(double), hipMemcpyDeviceToHost));
-  BK_HIP(hipMemcpyAsync(vals, dvalsH, k * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (refine) {
+    BK_TRY(gemm(ctx, 0, 0, n, k, n, 1.0, A, lda, Q, n, 0.0, KQ, n));
+    BK_TRY(gemm(ctx, 1, 0, k, k, n, 1.0, Q, n, KQ, n, 0.0, dH, k));
+    BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
+    int64_t nvZ = 0;
+    BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1, EIG_FULL));
+    BK_HIP(hipMemcpy(hv.data(), dvalsH, k * sizeof(double), hipMemcpyDeviceToHost));
+    dvals_final = dvalsH;
+  }
+  BK_HIP(hipMemcpyAsync(vals, dvals_final, k * sizeof(double), hipMemcpyDeviceToDevice, st));
   int64_t nv = 0;
   if (keep_thresh >= 0.0) {
     for (int64_t i = 0; i < k; ++i)
@@ -1922,7 +1978,8 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
   nv = std::min<int64_t>(nv, n_vecs_max);
   if (h_n_vecs) *h_n_vecs = nv;
   if (nv > 0) {
-    BK_TRY(gemm(ctx, 0, 0, n, nv, k, 1.0, Q, n, (double*)pZ, k, 0.0, vecs, ldv));
+    if (refine) BK_TRY(gemm(ctx, 0, 0, n, nv, k, 1.0, Q, n, (double*)pZ, k, 0.0, vecs, ldv));
+    else BK_TRY(copy_matrix(ctx, Q, n, nv, n, vecs, ldv));
     const int64_t pc0 = nv * part_index / part_count, pc1 = nv * (part_index + 1) / part_count;
     if (pc0 > 0) BK_HIP(hipMemsetAsync(vecs, 0, (size_t)pc0 * ldv * sizeof(double), st));
     if (pc1 < nv) BK_HIP(hipMemsetAsync(vecs + pc1 * ldv, 0, (size_t)(nv - pc1) * ldv * sizeof(double), st));
