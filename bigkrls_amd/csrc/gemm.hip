@@ -440,14 +440,16 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles_n = (g.N + BN - 1) / BN;
   const int ntile = tiles_m * tiles_n;
-  // split-K when the tile grid cannot fill 256 CUs and K is long
+  // split-K when the tile grid does not fill whole rounds of the GPU and K is long
   // The split count is chosen against the 512 workgroups the GPU holds at once (two per CU):
   // ntile * splits workgroups take ceil(ntile * splits / 512) rounds of K / splits k-steps each, plus
   // a per-split cost (prologue, partial store, reduction). A count that spills a few workgroups into
   // one more round pays that whole round: m = 20 000, n = 64 (157 tiles): 7 splits 1.02 ms, 6 or 3
   // splits 0.95 ms; m = 10 000 (79 tiles): 13 splits 0.30 ms, 6 splits 0.26 ms.
   int splits = 1;
-  if (ntile < 512 && g.K >= 1024) {
+  // (also above one round: 782 tiles -- N = 100 000 times a 128-column block -- fill 1.53 rounds unsplit,
+  //  i.e. run at 76 %; five splits fill 7.6 of 8)
+  if (ntile < 4096 && g.K >= 1024) {
     const int maxs = std::min(64, std::max(1, g.K / 256));
     // rough time model in us: a k-step of a workgroup ~0.06 us per unit of K; per split the partial
     // slab is written and read again (16 bytes per output element at ~5 TB/s) plus a fixed ~0.2 us
