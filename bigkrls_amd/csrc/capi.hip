@@ -65,11 +65,11 @@ int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes) {
   return BIGKRLS_OK;
 }
 
-int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap) {
+int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap, int threads) {
   for (auto& kv : ctx->resident_cap)
     if (kv.first == kernel) { *cap = kv.second; return BIGKRLS_OK; }
   int per_cu = 0, ncu = 0;
-  BK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+  BK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
   BK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
   *cap = std::max(1, per_cu * ncu);
   ctx->resident_cap.emplace_back(kernel, *cap);

@@ -149,8 +149,8 @@ int syrk_mirror_set(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const 
 int side_stream_get(bigkrls_ctx* ctx);
 // raise a kernel's dynamic shared-memory limit once per context (device)
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes);
-// co-resident workgroups of `kernel` (256 threads, static LDS only) on this context's device
-int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap);
+// co-resident workgroups of `kernel` (`threads` per workgroup, static LDS only) on this context's device
+int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap, int threads = 256);
 
 // effective sample size from the mean absolute pairwise row correlation (src/Neffective.cpp)
 int neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t p, double* h_out);

@@ -161,6 +161,16 @@ constexpr int SV_CW = 32;
 #endif
 constexpr int SV_B = BK_SV_B;    // column loads in flight per lane and batch
 
+// |(alpha, x)| from alpha and ss = |x|^2 (Householder: beta = -sign(alpha) |(alpha, x)|). ss is a plain sum of squares
+// already, so the scaled hypot only pays where alpha^2 + ss leaves the range in which the plain form is accurate; on
+// the latency chains of pq_resident / bc_resident (one reflector per column step / per hop) the square root of the
+// sum is ~40 dependent instructions shorter.
+__device__ __forceinline__ double hh_norm(double alpha, double ss) {
+  const double s2 = fma(alpha, alpha, ss);
+  if (s2 > 1e-280 && s2 < 1e280) return sqrt(s2);
+  return hypot(alpha, sqrt(ss));
+}
+
 template <int VEC> struct RowVec;
 template <> struct RowVec<1> { double v[1]; };
 template <> struct alignas(16) RowVec<2> { double v[2]; };
@@ -172,7 +182,7 @@ __device__ __forceinline__ void house_scalars(const double* __restrict__ part1, 
   if (ss == 0.0) {
     beta = alpha; t = 0.0; sc = 0.0;
   } else {
-    beta = -copysign(hypot(alpha, sqrt(ss)), alpha);
+    beta = -copysign(hh_norm(alpha, ss), alpha);
     t = (beta - alpha) / beta;
     sc = 1.0 / (alpha - beta);
   }
@@ -1665,46 +1675,96 @@ __global__ __launch_bounds__(256) void kry_resid_sq_kernel(const double* __restr
 constexpr int KRY_B = 128;
 __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ G, int b, double* __restrict__ Rout,
                                                             int* __restrict__ flag) {
-  __shared__ double A[KRY_B][KRY_B + 1];   // A[i][j], i <= j: R; i > j: inv(R)[j][i] (strictly upper part, transposed)
-  const int tid = threadIdx.x;
-  for (int e = tid; e < b * b; e += 256) {
-    const int i = e % b, j = e / b;
-    A[i][j] = 0.5 * (G[i + (int64_t)j * b] + G[j + (int64_t)i * b]);
+  // Register tiles: thread (ti, tj) of a 16 x 16 grid owns the entries (ti + 16 a, tj + 16 c), a, c = 0..7 (cyclic, so
+  // that the shrinking active part stays spread over all threads). Both phases are 128 rank-1 steps with ONE barrier
+  // each: the owners of row k publish it through a double-buffered LDS vector, everybody updates its 8 x 8 tile.
+  //   Cholesky (right-looking):  R[k][:] = A[k][:] / sqrt(A[k][k]);  A[i][j] -= R[k][i] R[k][j]
+  //   inverse (Gauss-Jordan on [R | I], k descending):  X[k][:] /= R[k][k];  X[i][:] -= R[i][k] X[k][:]  (i < k)
+  // Rows and columns >= b are padded with the identity. (The previous version -- one LDS element at a time with an
+  // integer division per element, then one thread per column of the inverse -- took 0.6 ms per call, twice per
+  // Lanczos step on the critical path.)
+  __shared__ double sR[KRY_B][KRY_B + 1];
+  __shared__ double rowk[2][KRY_B];
+  const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+  double t[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = ti + 16 * a, j = tj + 16 * c;
+      t[a][c] = (i < b && j < b) ? 0.5 * (G[i + (int64_t)j * b] + G[j + (int64_t)i * b]) : (i == j ? 1.0 : 0.0);
+    }
+  for (int e = tid; e < KRY_B * (KRY_B + 1); e += 256) (&sR[0][0])[e] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int ka = 0; ka < 8; ++ka) {
+    for (int kt = 0; kt < 16; ++kt) {
+      const int k = 16 * ka + kt;
+      double* rk = rowk[k & 1];
+      if (ti == kt) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rk[tj + 16 * c] = t[ka][c];
+      }
+      __syncthreads();
+      const double d = rk[k];
+      if (!(d > 0.0) || !isfinite(d)) {   // uniform
+        if (tid == 0) *flag = 1;
+        return;
+      }
+      const double rinv = 1.0 / sqrt(d);
+      double ri[8], rj[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) ri[a] = rk[ti + 16 * a] * rinv;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) rj[c] = rk[tj + 16 * c] * rinv;
+      if (tid < KRY_B && tid >= k) sR[k][tid] = rk[tid] * rinv;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t[a][c] = fma(-ri[a], rj[c], t[a][c]);   // (entries in rows / columns <= k are dead)
+    }
   }
   __syncthreads();
-  for (int k = 0; k < b; ++k) {
-    const double d = A[k][k];
-    if (!(d > 0.0) || !isfinite(d)) {   // uniform
-      if (tid == 0) *flag = 1;
-      return;
+  // ---- X = inv(R) ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t[a][c] = (ti + 16 * a == tj + 16 * c) ? 1.0 : 0.0;
+#pragma unroll
+  for (int ka = 7; ka >= 0; --ka) {
+    for (int kt = 15; kt >= 0; --kt) {
+      const int k = 16 * ka + kt;
+      double* rk = rowk[k & 1];
+      if (ti == kt) {
+        const double dinv = 1.0 / sR[k][k];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          t[ka][c] *= dinv;
+          rk[tj + 16 * c] = t[ka][c];
+        }
+      }
+      __syncthreads();
+      double f[8], xk[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) f[a] = (ti + 16 * a < k) ? sR[ti + 16 * a][k] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xk[c] = rk[tj + 16 * c];
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t[a][c] = fma(-f[a], xk[c], t[a][c]);
     }
-    const double r = sqrt(d);
-    __syncthreads();                    // everybody has read the pivot
-    for (int j = k + tid; j < b; j += 256) A[k][j] = (j == k) ? r : A[k][j] / r;
-    __syncthreads();
-    const int nt = b - k - 1;
-    for (int e = tid; e < nt * nt; e += 256) {
-      const int i = k + 1 + e / nt, j = k + 1 + e % nt;
-      if (j >= i) A[i][j] -= A[k][i] * A[k][j];
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = ti + 16 * a, j = tj + 16 * c;
+      if (i < b && j < b) {
+        G[i + (int64_t)j * b] = (i <= j) ? t[a][c] : 0.0;
+        Rout[i + (int64_t)j * b] = (i <= j) ? sR[i][j] : 0.0;
+      }
     }
-    __syncthreads();
-  }
-  // inv(R): column j by back substitution, one thread per column; X[i][j] (i < j) is kept at A[j][i]
-  if (tid < b) {
-    const int j = tid;
-    const double xjj = 1.0 / A[j][j];
-    for (int i = j - 1; i >= 0; --i) {
-      double s = A[i][j] * xjj;
-      for (int kk = i + 1; kk < j; ++kk) s += A[i][kk] * A[j][kk];
-      A[j][i] = -s / A[i][i];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < b * b; e += 256) {
-    const int i = e % b, j = e / b;
-    Rout[i + (int64_t)j * b] = (i <= j) ? A[i][j] : 0.0;
-    G[i + (int64_t)j * b] = (i < j) ? A[j][i] : ((i == j) ? 1.0 / A[i][i] : 0.0);
-  }
 }
 
 // The projected block-tridiagonal matrix T (m x m, m = steps * b) from the blocks kept on the device:
@@ -2372,3 +2432,15 @@ int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int
 }
 
 }  // namespace bk
+
+#ifdef BK_BC_PROF
+// profiling builds only (tools/bc_prof.py): the accumulated shader clocks of one bc_resident location per phase
+extern "C" int bigkrls_debug_bc_prof(long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(bk::bc_prof_acc), 8 * sizeof(long long)) != hipSuccess) return 1;
+  if (reset) {
+    long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bk::bc_prof_acc), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

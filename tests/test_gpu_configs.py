@@ -352,6 +352,34 @@ def test_eigen_watchdog_retry_and_lanczos_fallback(ctx, monkeypatch):
     assert res < 1e-11 and orth < 1e-11
 
 
+def test_lanczos_sampled_verification_matches_full_rayleigh_ritz(ctx, monkeypatch):
+    """The block Lanczos returns the Ritz pairs of its projected matrix after checking the true residual
+    K q - theta q on the block of pairs that converges last; BIGKRLS_KRY_REFINE=1 refines all pairs by a
+    Rayleigh-Ritz step against K instead (what every call did before, and the fallback when that check fails).
+    Same eigenvalues to the square of the residual level, kept eigenvectors at rounding-level residual and
+    orthogonality either way, and the same fit."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    n, p, k = 16384, 6, 160
+    X, y = orc.synth(n, p, 12)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    fast = ops.bEigen(K, k, 0.001)
+    monkeypatch.setenv("BIGKRLS_KRY_REFINE", "1")
+    full = ops.bEigen(K, k, 0.001)
+    fit_full = bk.bigKRLS(y, X, Neig=k, ctx=ctx)
+    monkeypatch.delenv("BIGKRLS_KRY_REFINE")
+    fit_fast = bk.bigKRLS(y, X, Neig=k, ctx=ctx)
+    assert fast.lastkeeper == full.lastkeeper
+    assert rel(fast.values, full.values) < 1e-11
+    for e in (fast, full):
+        res, orth = eigen_quality(ops, K, e.vectors, e.values)
+        assert res < 1e-9 and orth < 1e-11, (res, orth)
+    assert rel(fit_fast["coeffs"], fit_full["coeffs"]) < 1e-8
+    assert rel(fit_fast["derivatives"], fit_full["derivatives"]) < 1e-8
+    assert fit_fast["lambda"] == pytest.approx(fit_full["lambda"], rel=1e-9)
+
+
 def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatch):
     """Stage 1 above 14848 trailing rows applies the trailing update for two panels at once (k = 256),
     as two pieces of equal area with thin corrections of everything that reads the stale matrix
