@@ -327,8 +327,10 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     Ball[:b] = Bj
     Ablk, Bblk = [], []
     steps, converged, Y, theta = 0, False, None, None
-    next_check = max(2, (4 * neig + b - 1) // b)
-    prev_worst, prev_steps = -1.0, 0
+    # the check schedule of csrc/eigen.hip (sizes only, so that every rank and every run decides alike): the first
+    # check at a subspace of 4 neig columns, or of 2 neig where a step costs more than a check
+    check_is_cheap = 12e-6 * 4.0 * neig < 2.0 * float(n) * float(n) * b / 50e12 / max(world, 1)
+    next_check = max(2, ((2 if check_is_cheap else 4) * neig + b - 1) // b)
     while True:
         _t0 = _t.perf_counter()
         W = k_times(Ball[steps * b:(steps + 1) * b])
@@ -372,27 +374,39 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             if worst <= tol * theta1 or last:
                 converged = worst <= tol * theta1
                 break
-            inc = max(2, steps // 6)                                 # same schedule as csrc/eigen.hip
-            if prev_worst > 0.0 and 0.0 < worst < prev_worst:
-                rate = math.log(worst / prev_worst) / (steps - prev_steps)
-                need = math.log(tol * theta1 / worst) / rate
-                if math.isfinite(need) and need > 0.0:
-                    inc = max(1, min(int(math.ceil(need)) + 1, 4 * inc))
-            prev_worst, prev_steps = worst, steps
-            next_check = steps + inc
+            # distance to the tolerance at the collapse rate of the worst residual (x25 - x45 per step once the
+            # subspace reaches the neig-th eigenvalue; csrc/eigen.hip has the measurements)
+            gain = 40.0 if check_is_cheap else 15.0
+            inc = int(math.ceil(math.log(worst / (tol * theta1)) / math.log(gain))) if worst > 0.0 else 1
+            next_check = steps + max(1, min(inc, max(2, steps // 2)))
             _tick("check", _t0); _t0 = _t.perf_counter()
         Ball[steps * b:(steps + 1) * b] = W
     if not converged:
         raise RuntimeError("eigen_krylov_dist: not converged within the subspace limit")
     dim = steps * b
     Q = backend.mm(False, False, Ball[:dim], Y)                       # n x neig
-    KQ = k_times(Q)
-    H = _host(backend, backend.mm(True, False, Q, KQ)).T
-    H = 0.5 * (H + H.T)
-    hv, Zr = backend.dense_eig_top(H, neig)
-    vals = np.asarray(hv[:neig], dtype=np.float64)
+    # The Ritz pairs of T are verified against K on the block that converges last (the smallest min(neig, b)
+    # Ritz values: one more sharded product); only if the true residuals are not at the estimated level are all
+    # pairs refined by a Rayleigh-Ritz step against K (as csrc/eigen.hip; BIGKRLS_KRY_REFINE=1 forces it).
+    refine = os.environ.get("BIGKRLS_KRY_REFINE") == "1"
+    vals = np.asarray(theta[:neig], dtype=np.float64)
+    if not refine:
+        bs = min(neig, b)
+        Qs = Q[neig - bs:].contiguous()
+        Rs = k_times(Qs)
+        Rs = backend.mm(False, False, Qs, backend.from_numpy(np.diag(vals[neig - bs:])), alpha=-1.0, beta=1.0, out=Rs)
+        r2 = np.diag(_host(backend, backend.mm(True, False, Rs, Rs)))
+        rmax = float(np.sqrt(max(float(np.max(r2)), 0.0)))
+        neg_r, theta1 = agree_min([-rmax, abs(float(vals[0]))])
+        refine = not (-neg_r <= 10.0 * tol * theta1)
+    if refine:
+        KQ = k_times(Q)
+        H = _host(backend, backend.mm(True, False, Q, KQ)).T
+        H = 0.5 * (H + H.T)
+        hv, Zr = backend.dense_eig_top(H, neig)
+        vals = np.asarray(hv[:neig], dtype=np.float64)
     lastkeeper = int(np.max(np.nonzero(vals >= eigtrunc * vals[0])[0])) + 1
-    Qf = backend.mm(False, False, Q, Zr[:lastkeeper])
+    Qf = backend.mm(False, False, Q, Zr[:lastkeeper]) if refine else Q[:lastkeeper].contiguous()
     if _prof is not None and rank == 0:
         print("[bigkrls] eigen_krylov_dist steps=%d dim=%d" % (steps, dim), {kk: round(v, 3) for kk, v in _prof.items()}, flush=True)
     return vals, lastkeeper, Qf, backend.from_numpy(vals[:, None])

@@ -1,6 +1,9 @@
 import sys, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 3:
+    import bigkrls_amd._lib as L
+    L.LIB_PATH = os.path.abspath(sys.argv[3])      # A/B: another build of the library
 import bigkrls_amd as bk
 from bigkrls_amd import ops
 n, p = int(sys.argv[1]), int(sys.argv[2])
