@@ -57,6 +57,24 @@ int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out) {
   return BIGKRLS_OK;
 }
 
+int PinnedFetch::add(void* host_dst, const void* dev_src, size_t bytes) {
+  if (!base_) BK_TRY(pinned_get(ctx_, cap_, &base_));
+  const size_t nd = (bytes + 7) / 8;
+  BK_REQUIRE((int64_t)(used_ + nd) <= cap_, "PinnedFetch: capacity exceeded");
+  BK_HIP(hipMemcpyAsync(base_ + used_, dev_src, bytes, hipMemcpyDeviceToHost, ctx_->stream));
+  items_.push_back({host_dst, used_, bytes});
+  used_ += nd;
+  return BIGKRLS_OK;
+}
+
+int PinnedFetch::finish() {
+  BK_HIP(hipStreamSynchronize(ctx_->stream));
+  for (const Item& it : items_) std::memcpy(it.dst, base_ + it.off, it.bytes);
+  items_.clear();
+  used_ = 0;
+  return BIGKRLS_OK;
+}
+
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes) {
   for (const void* k : ctx->dyn_smem_done)
     if (k == kernel) return BIGKRLS_OK;

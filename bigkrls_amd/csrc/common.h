@@ -123,6 +123,24 @@ int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
 int prof_begin(bigkrls_ctx* ctx, const char* name, double work, hipStream_t stream = nullptr);
 int prof_end(bigkrls_ctx* ctx, const char* name, hipStream_t stream = nullptr);
 int pinned_get(bigkrls_ctx* ctx, int64_t ndoubles, double** out);
+// Device -> host read-backs of a few small arrays through the context's pinned buffer: add() enqueues a copy into
+// the next slice, finish() synchronises the stream and moves the slices to their destinations. (An asynchronous
+// copy into pageable memory makes the runtime pin and unpin the user pages; inside loops that showed up as
+// sporadic stalls of 1-2 s.) `capacity_doubles` must cover everything added before finish().
+class PinnedFetch {
+ public:
+  PinnedFetch(bigkrls_ctx* ctx, int64_t capacity_doubles) : ctx_(ctx), cap_(capacity_doubles) {}
+  int add(void* host_dst, const void* dev_src, size_t bytes);
+  int finish();
+
+ private:
+  struct Item { void* dst; size_t off, bytes; };
+  bigkrls_ctx* ctx_;
+  int64_t cap_;
+  double* base_ = nullptr;
+  size_t used_ = 0;   // doubles
+  std::vector<Item> items_;
+};
 
 // ---- gemm.hip -----------------------------------------------------------------
 int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha,

@@ -1098,9 +1098,10 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                          (const double*)d_w, Q0, Q1, N, d_lam, d_fail);
       BK_CHECK_LAUNCH();
       int h_fail = 0;
-      BK_HIP(hipMemcpyAsync(hlam.data(), d_lam, n * sizeof(double), hipMemcpyDeviceToHost, st));
-      BK_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-      BK_HIP(hipStreamSynchronize(st));
+      PinnedFetch pf(ctx, (int64_t)n + 1);
+      BK_TRY(pf.add(hlam.data(), d_lam, n * sizeof(double)));
+      BK_TRY(pf.add(&h_fail, d_fail, sizeof(int)));
+      BK_TRY(pf.finish());
       if (h_fail != 0) {
         set_error("eigen: the QL iteration of a divide & conquer leaf did not converge");
         return BIGKRLS_ENOCONV;
@@ -1161,12 +1162,13 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                              (const MergeDesc*)(d_descs + b0), (const double*)Qc, N, d_gf, d_gl);
       }
       BK_CHECK_LAUNCH();
-      BK_HIP(hipMemcpyAsync(hz.data(), d_z, n * sizeof(double), hipMemcpyDeviceToHost, st));
+      PinnedFetch pf(ctx, 3 * (int64_t)n);
+      BK_TRY(pf.add(hz.data(), d_z, n * sizeof(double)));
       if (lazy_level) {
-        BK_HIP(hipMemcpyAsync(yf.data(), d_gf, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        BK_HIP(hipMemcpyAsync(yl.data(), d_gl, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_TRY(pf.add(yf.data(), d_gf, n * sizeof(double)));
+        BK_TRY(pf.add(yl.data(), d_gl, n * sizeof(double)));
       }
-      BK_HIP(hipStreamSynchronize(st));
+      BK_TRY(pf.finish());
     } else {
       for (int q = 0; q < nm; ++q) {
         const MergeDesc& md = descs[q];
@@ -1255,7 +1257,9 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                            (const double*)U, N, d_zhat);
       }
       BK_CHECK_LAUNCH();
-      BK_HIP(hipMemcpyAsync(hlam.data(), d_lam, n * sizeof(double), hipMemcpyDeviceToHost, st));
+      PinnedFetch pf(ctx, (int64_t)n);
+      BK_TRY(pf.add(hlam.data(), d_lam, n * sizeof(double)));
+      BK_TRY(pf.finish());
     }
     BK_HIP(hipStreamSynchronize(st));
     // new eigenvalue lists in storage order
@@ -1358,9 +1362,10 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
           BK_CHECK_LAUNCH();
         }
         std::vector<double> ofh(n), olh(n);
-        BK_HIP(hipMemcpyAsync(ofh.data(), d_of, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        BK_HIP(hipMemcpyAsync(olh.data(), d_ol, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        BK_HIP(hipStreamSynchronize(st));
+        PinnedFetch pf(ctx, 2 * (int64_t)n);
+        BK_TRY(pf.add(ofh.data(), d_of, n * sizeof(double)));
+        BK_TRY(pf.add(olh.data(), d_ol, n * sizeof(double)));
+        BK_TRY(pf.finish());
         for (int q = 0; q < nm; ++q) {
           const MergeDesc& md = descs[q];
           for (int j = 0; j < md.K; ++j) { bf[md.s + j] = ofh[md.s + j]; bl[md.s + j] = olh[md.s + j]; }
@@ -2024,7 +2029,11 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
     int64_t nvZ = 0;
     BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1, EIG_FULL));
-    BK_HIP(hipMemcpy(hv.data(), dvalsH, k * sizeof(double), hipMemcpyDeviceToHost));
+    {
+      PinnedFetch pf(ctx, k);
+      BK_TRY(pf.add(hv.data(), dvalsH, k * sizeof(double)));
+      BK_TRY(pf.finish());
+    }
     dvals_final = dvalsH;
   }
   BK_HIP(hipMemcpyAsync(vals, dvals_final, k * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2217,8 +2226,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     {
       // watchdog word of the register-resident panel QR: checked before stage 2 consumes the band
       int h_err1 = 0;
-      BK_HIP(hipMemcpyAsync(&h_err1, s1.err, sizeof(int), hipMemcpyDeviceToHost, st));
-      BK_HIP(hipStreamSynchronize(st));
+      PinnedFetch pf1(ctx, 1);
+      BK_TRY(pf1.add(&h_err1, s1.err, sizeof(int)));
+      BK_TRY(pf1.finish());
       // BIGKRLS_FAULT=watchdog (tests): pretend the watchdog fired on the first attempt
       const char* fault = getenv("BIGKRLS_FAULT");
       if (fault && std::string(fault) == "watchdog" && !ctx->no_resident) h_err1 = 1;
@@ -2265,8 +2275,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
     }
     int h_err = 0;
-    BK_HIP(hipMemcpyAsync(&h_err, bc_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    BK_HIP(hipStreamSynchronize(st));  // plan.soff (host) was the source of an async copy
+    PinnedFetch pf2(ctx, 1);
+    BK_TRY(pf2.add(&h_err, bc_err, sizeof(int)));
+    BK_TRY(pf2.finish());              // (also: plan.soff (host) was the source of an async copy)
     tick("stage 2 (band -> tridiagonal)");
     // T factors of the stage-2 back-transform tasks (BIGKRLS_BT2=seq: reflector-by-reflector kernel)
     const char* bt2_env = getenv("BIGKRLS_BT2");
@@ -2303,9 +2314,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(d, W, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   std::vector<double> hd(n), he(n);
-  BK_HIP(hipMemcpyAsync(hd.data(), d, N * sizeof(double), hipMemcpyDeviceToHost, st));
-  BK_HIP(hipMemcpyAsync(he.data(), e, N * sizeof(double), hipMemcpyDeviceToHost, st));
-  BK_HIP(hipStreamSynchronize(st));
+  {
+    PinnedFetch pf(ctx, 2 * N);
+    BK_TRY(pf.add(hd.data(), d, N * sizeof(double)));
+    BK_TRY(pf.add(he.data(), e, N * sizeof(double)));
+    BK_TRY(pf.finish());
+  }
   for (int i = 0; i < n; ++i)
     if (!std::isfinite(hd[i]) || (i < n - 1 && !std::isfinite(he[i]))) {
       set_error("eigen: non-finite entries after tridiagonalisation (NaN/Inf in the input?)");

@@ -136,8 +136,9 @@ int neffective(bigkrls_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_
                      partial + ntiles);
   BK_CHECK_LAUNCH();
   double r = 0.0;
-  BK_HIP(hipMemcpyAsync(&r, partial + ntiles, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  BK_HIP(hipStreamSynchronize(ctx->stream));
+  PinnedFetch pf(ctx, 1);
+  BK_TRY(pf.add(&r, partial + ntiles, sizeof(double)));
+  BK_TRY(pf.finish());
   const double N = (double)n;
   const double mean_abs_cor = 2.0 * r / (N * N);   // src/Neffective.cpp:61
   *h_out = N * (1.0 - mean_abs_cor) + 1.0;         // :64
