@@ -92,6 +92,13 @@ int main(int argc, char** argv) {
     run("idle", [&] {});
     run("A22 V (tall)", [&] { gemm(ctx, 0, 0, m, 64, m, 1.0, A22, N, V, m, 0.0, Y1, m); });
     run("read-only tall pattern", [&] { hipLaunchKernelGGL(read_tall, dim3(156, 4), dim3(256), 0, st, A22, N, (int)m, 5024, Y0); });
+    {
+      double *PA, *PB; hipMalloc(&PA, m * 512 * 8); hipMalloc(&PB, m * 512 * 8);
+      fillr<<<2048, 256, 0, st>>>(PA, m * 512, 5); fillr<<<2048, 256, 0, st>>>(PB, m * 512, 6);
+      run("syrk_mirror<64> k=128", [&] { syrk_mirror(ctx, m, 128, -1.0, PA, m, PB, m, A, N, 0, -1, true); });
+      run("syrk_mirror<64> k=256", [&] { syrk_mirror(ctx, m, 256, -1.0, PA, m, PB, m, A, N, 0, -1, true); });
+      hipFree(PA); hipFree(PB);
+    }
     run("gemm NN 8192^3", [&] { gemm(ctx, 0, 0, 8192, 8192, 8192, 1.0, A, 8192, A + 8192 * 8192, 8192, 0.0, A + 2 * 8192 * 8192, 8192); });
     fillr<<<2048, 256, 0, st>>>(A, N * N, 1);
     hipDeviceSynchronize();
