@@ -474,6 +474,15 @@ int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double
                part_count, EIG_RESUME);
 }
 
+int bigkrls_dev_cholqr2(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int64_t b, double* h_R,
+                        int32_t* h_breakdown) {
+  BK_TRY(check_ctx(ctx));
+  int brk = 0;
+  const int rc = cholqr2_block(ctx, W, tmp, n, (int)b, h_R, &brk);
+  if (h_breakdown) *h_breakdown = brk;
+  return rc;
+}
+
 int bigkrls_dev_copy_matrix(bigkrls_ctx* ctx, const double* src, int64_t m, int64_t n, int64_t lds,
                             double* dst, int64_t ldd) {
   BK_TRY(check_ctx(ctx));

@@ -231,6 +231,10 @@ int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int6
                double* Yout, int64_t ldy);
 int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
                    int64_t row0);
+// Cholesky-QR twice of the n x b block W (b <= 128) on the device (Gram product, register-tile Cholesky + inverse,
+// W R^-1), in place with `tmp` (n x b) as scratch; h_R (b x b, host, column-major) receives R = R2 R1,
+// *h_breakdown is set when a pivot was not positive. Synchronises the stream. (csrc/eigen.hip)
+int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown);
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
 
 }  // namespace bk

@@ -1831,6 +1831,20 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
 
 }  // namespace
 
+int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown) {
+  BK_REQUIRE(W && tmp && h_R && h_breakdown && n > 0 && b > 0 && b <= KRY_B, "cholqr2_block: bad arguments");
+  void* pg = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_KRY_C, (5 * (int64_t)b * b + 8) * sizeof(double), &pg));
+  std::vector<double> R;
+  bool breakdown = false;
+  double *w = W, *t = tmp;
+  BK_TRY(kry_cholqr(ctx, &w, &t, n, b, (double*)pg, R, &breakdown));   // two swaps: the result is back in W
+  std::memcpy(h_R, R.data(), (size_t)b * b * sizeof(double));
+  *h_breakdown = breakdown ? 1 : 0;
+  return BIGKRLS_OK;
+}
+
+
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
           int part_index, int part_count, int mode);

@@ -207,6 +207,18 @@ class HipBackend:
         k = int(nv.value)
         return vals.to_numpy().ravel(), k, vecs.t[:k], vals.t
 
+    def cholqr2(self, W):
+        """Orthonormalise the rows of the (b, n) tensor W (the columns of the n x b block) on the device, in
+        place: (W, R host (b, b) upper triangular with W_in = W_out R, ok)."""
+        b, n = W.shape
+        assert W.is_contiguous()
+        tmp = self.torch.empty_like(W)
+        R = np.empty((b, b), dtype=np.float64, order="F")
+        brk = C.c_int32(0)
+        _lib.call("bigkrls_dev_cholqr2", self.ctx.handle, C.c_void_p(W.data_ptr()), C.c_void_p(tmp.data_ptr()), n, b,
+                  R.ctypes.data_as(C.c_void_p), C.byref(brk))
+        return W, (None if brk.value else np.ascontiguousarray(R)), brk.value == 0
+
     def dense_eig_top(self, T, k):
         """All eigenvalues (descending, host) and the top-k eigenvectors (tensor (k, m)) of the dense
         symmetric T given as a host array."""
@@ -290,7 +302,11 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         return full.view(world, cols, nb).permute(1, 0, 2).reshape(cols, world * nb)[:, :n].contiguous()
 
     def cholqr2(W):
-        """Orthonormalise the columns of W (tensor (b, n)); returns (Q, R host upper, ok)."""
+        """Orthonormalise the columns of W (tensor (b, n)); returns (Q, R host upper, ok). The HIP backend does it
+        on the device (the library's Gram product + register-tile Cholesky / inverse); a backend without
+        `cholqr2` (the numpy double of the gloo tests) goes through its products and a host Cholesky."""
+        if hasattr(backend, "cholqr2"):
+            return backend.cholqr2(W.contiguous())
         Racc = None
         for _ in range(2):
             G = _host(backend, backend.mm(True, False, W, W)).T         # b x b
