@@ -474,11 +474,22 @@ int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double
                part_count, EIG_RESUME);
 }
 
+int bigkrls_dev_fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed) {
+  BK_TRY(check_ctx(ctx));
+  return fill_random(ctx, p, count, seed);
+}
+
+int bigkrls_dev_lanczos_projected(bigkrls_ctx* ctx, const double* d_A_blocks, const double* d_beta_blocks,
+                                  int64_t steps, int64_t b, double* d_T) {
+  BK_TRY(check_ctx(ctx));
+  return lanczos_projected(ctx, d_A_blocks, d_beta_blocks, (int)steps, (int)b, d_T);
+}
+
 int bigkrls_dev_cholqr2(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int64_t b, double* h_R,
-                        int32_t* h_breakdown) {
+                        int32_t* h_breakdown, double* d_R) {
   BK_TRY(check_ctx(ctx));
   int brk = 0;
-  const int rc = cholqr2_block(ctx, W, tmp, n, (int)b, h_R, &brk);
+  const int rc = cholqr2_block(ctx, W, tmp, n, (int)b, h_R, &brk, d_R);
   if (h_breakdown) *h_breakdown = brk;
   return rc;
 }

@@ -231,10 +231,18 @@ int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int6
                double* Yout, int64_t ldy);
 int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
                    int64_t row0);
+// p[0 .. count) = uniform values in [-0.5, 0.5) from a counter-based generator (element index and seed only): the
+// start block of the block Lanczos, identical on every device
+int fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed);
 // Cholesky-QR twice of the n x b block W (b <= 128) on the device (Gram product, register-tile Cholesky + inverse,
 // W R^-1), in place with `tmp` (n x b) as scratch; h_R (b x b, host, column-major) receives R = R2 R1,
 // *h_breakdown is set when a pivot was not positive. Synchronises the stream. (csrc/eigen.hip)
-int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown);
+int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown,
+                  double* d_R = nullptr);
+// T (m x m, m = steps b, column-major, device) = the block-tridiagonal projected matrix of a block Lanczos run from
+// its diagonal blocks A_j (symmetrised) and sub-diagonal factors beta_{j+1} (upper triangular), b x b each
+int lanczos_projected(bigkrls_ctx* ctx, const double* d_A_blocks, const double* d_beta_blocks, int steps, int b,
+                      double* d_T);
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
 
 }  // namespace bk

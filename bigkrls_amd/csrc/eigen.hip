@@ -1831,14 +1831,33 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
 
 }  // namespace
 
-int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown) {
+int fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed) {
+  BK_REQUIRE(p && count >= 0, "fill_random: bad arguments");
+  if (count == 0) return BIGKRLS_OK;
+  hipLaunchKernelGGL(kry_fill_random, dim3(2048), dim3(256), 0, ctx->stream, p, count, (unsigned)seed);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
+int lanczos_projected(bigkrls_ctx* ctx, const double* d_A_blocks, const double* d_beta_blocks, int steps, int b,
+                      double* d_T) {
+  BK_REQUIRE(d_A_blocks && d_T && steps >= 1 && b >= 1 && (steps == 1 || d_beta_blocks), "lanczos_projected: bad arguments");
+  const int64_t m = (int64_t)steps * b;
+  hipLaunchKernelGGL(kry_assemble_t, dim3((unsigned)std::min<int64_t>((m * m + 255) / 256, 8192)), dim3(256), 0,
+                     ctx->stream, d_A_blocks, d_beta_blocks, steps, b, d_T);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
+int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, double* h_R, int* h_breakdown,
+                  double* d_R) {
   BK_REQUIRE(W && tmp && h_R && h_breakdown && n > 0 && b > 0 && b <= KRY_B, "cholqr2_block: bad arguments");
   void* pg = nullptr;
   BK_TRY(ws_get(ctx, SLOT_KRY_C, (5 * (int64_t)b * b + 8) * sizeof(double), &pg));
   std::vector<double> R;
   bool breakdown = false;
   double *w = W, *t = tmp;
-  BK_TRY(kry_cholqr(ctx, &w, &t, n, b, (double*)pg, R, &breakdown));   // two swaps: the result is back in W
+  BK_TRY(kry_cholqr(ctx, &w, &t, n, b, (double*)pg, R, &breakdown, d_R));   // two swaps: the result is back in W
   std::memcpy(h_R, R.data(), (size_t)b * b * sizeof(double));
   *h_breakdown = breakdown ? 1 : 0;
   return BIGKRLS_OK;
@@ -1877,8 +1896,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
   std::vector<double> Rtmp;                        // beta of the last step (host copy, for the Ritz residuals)
   bool breakdown = false;
   // ---- B_0 ----------------------------------------------------------------------------------
-  hipLaunchKernelGGL(kry_fill_random, dim3(2048), dim3(256), 0, st, W, n * b, 20240229u);
-  BK_CHECK_LAUNCH();
+  BK_TRY(fill_random(ctx, W, n * b, 20240229u));
   BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown));
   BK_REQUIRE(!breakdown, "eigen (Krylov): start block is rank deficient");
   BK_HIP(hipMemcpyAsync(B, W, n * b * sizeof(double), hipMemcpyDeviceToDevice, st));

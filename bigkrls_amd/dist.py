@@ -207,17 +207,36 @@ class HipBackend:
         k = int(nv.value)
         return vals.to_numpy().ravel(), k, vecs.t[:k], vals.t
 
-    def cholqr2(self, W):
+    def random_block(self, b, n, seed):
+        """(b, n) tensor of uniform values in [-0.5, 0.5) that depend on the position and the seed only."""
+        W = self.torch.empty((b, n), dtype=self.torch.float64, device=self.device)
+        _lib.call("bigkrls_dev_fill_random", self.ctx.handle, C.c_void_p(W.data_ptr()), b * n, int(seed) & 0xFFFFFFFF)
+        return W
+
+    def cholqr2(self, W, R_dev=None):
         """Orthonormalise the rows of the (b, n) tensor W (the columns of the n x b block) on the device, in
-        place: (W, R host (b, b) upper triangular with W_in = W_out R, ok)."""
+        place: (W, R host (b, b) upper triangular with W_in = W_out R, ok). R_dev: optional (b, b) device tensor
+        that receives R in the library's column-major layout."""
         b, n = W.shape
         assert W.is_contiguous()
         tmp = self.torch.empty_like(W)
         R = np.empty((b, b), dtype=np.float64, order="F")
         brk = C.c_int32(0)
         _lib.call("bigkrls_dev_cholqr2", self.ctx.handle, C.c_void_p(W.data_ptr()), C.c_void_p(tmp.data_ptr()), n, b,
-                  R.ctypes.data_as(C.c_void_p), C.byref(brk))
+                  R.ctypes.data_as(C.c_void_p), C.byref(brk),
+                  C.c_void_p(R_dev.data_ptr()) if R_dev is not None else None)
         return W, (None if brk.value else np.ascontiguousarray(R)), brk.value == 0
+
+    def projected_eig_top(self, A_blocks, beta_blocks, steps, k):
+        """Eigenvalues (descending, host) and top-k eigenvectors (tensor (k, m)) of the block-tridiagonal projected
+        matrix assembled on the device from the (maxsteps, b, b) block tensors."""
+        b = A_blocks.shape[1]
+        m = steps * b
+        Tm = self.ctx.empty(m, m)
+        _lib.call("bigkrls_dev_lanczos_projected", self.ctx.handle, C.c_void_p(A_blocks.data_ptr()),
+                  C.c_void_p(beta_blocks.data_ptr()), steps, b, Tm.ptr)
+        eo = ops.bEigen(Tm, m, -1.0)
+        return eo.values, eo.vectors.t[:k]
 
     def dense_eig_top(self, T, k):
         """All eigenvalues (descending, host) and the top-k eigenvectors (tensor (k, m)) of the dense
@@ -301,12 +320,12 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         dist.all_gather_into_tensor(full, Wloc.contiguous())
         return full.view(world, cols, nb).permute(1, 0, 2).reshape(cols, world * nb)[:, :n].contiguous()
 
-    def cholqr2(W):
+    def cholqr2(W, R_dev=None):
         """Orthonormalise the columns of W (tensor (b, n)); returns (Q, R host upper, ok). The HIP backend does it
         on the device (the library's Gram product + register-tile Cholesky / inverse); a backend without
         `cholqr2` (the numpy double of the gloo tests) goes through its products and a host Cholesky."""
         if hasattr(backend, "cholqr2"):
-            return backend.cholqr2(W.contiguous())
+            return backend.cholqr2(W.contiguous(), R_dev)
         Racc = None
         for _ in range(2):
             G = _host(backend, backend.mm(True, False, W, W)).T         # b x b
@@ -334,14 +353,25 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             backend.sync()
             _prof[name] = _prof.get(name, 0.0) + (_t.perf_counter() - t0)
 
-    rng = np.random.default_rng(seed)
-    W0 = backend.from_numpy(rng.random((n, b)) - 0.5)
+    _t0 = _t.perf_counter()
+    if hasattr(backend, "random_block"):                 # on the device: the single-GPU library's start block
+        W0 = backend.random_block(b, n, seed)
+    else:
+        rng = np.random.default_rng(seed)
+        W0 = backend.from_numpy(rng.random((n, b)) - 0.5)
     Bj, _, ok = cholqr2(W0)
     if not agree_min([1.0 if ok else 0.0])[0] > 0.5:
         raise RuntimeError("eigen_krylov_dist: start block is rank deficient")
     Ball = torch.empty((maxdim, n), dtype=torch.float64, device=Bj.device)
     Ball[:b] = Bj
+    _tick("start block", _t0)
     Ablk, Bblk = [], []
+    # with the HIP backend the blocks of the projected matrix stay on the device (as in csrc/eigen.hip): no per-step
+    # read-back of A_j, no host assembly / upload of T at a check
+    dev_blocks = hasattr(backend, "projected_eig_top")
+    if dev_blocks:
+        A_dev = torch.zeros((maxsteps, b, b), dtype=torch.float64, device=Bj.device)
+        beta_dev = torch.zeros((maxsteps, b, b), dtype=torch.float64, device=Bj.device)
     steps, converged, Y, theta = 0, False, None, None
     # the check schedule of csrc/eigen.hip (sizes only, so that every rank and every run decides alike): the first
     # check at a subspace of 4 neig columns, or of 2 neig where a step costs more than a check
@@ -357,12 +387,16 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         for pas in range(2):                                          # classical Gram-Schmidt, twice
             Cc = backend.mm(True, False, Bv, W)                       # dim x b
             if pas == 0:
-                Aj = _host(backend, Cc[:, steps * b:(steps + 1) * b]).T.copy()
+                if dev_blocks:
+                    A_dev[steps].copy_(Cc[:, steps * b:(steps + 1) * b])     # (column, row) = column-major A_j
+                else:
+                    Aj = _host(backend, Cc[:, steps * b:(steps + 1) * b]).T.copy()
             W = backend.mm(False, False, Bv, Cc, alpha=-1.0, beta=1.0, out=W)
         _tick("cgs2", _t0); _t0 = _t.perf_counter()
-        W, R, ok = cholqr2(W)
+        W, R, ok = cholqr2(W, beta_dev[steps] if dev_blocks else None)
         _tick("cholqr2", _t0); _t0 = _t.perf_counter()
-        Ablk.append(0.5 * (Aj + Aj.T))
+        if not dev_blocks:
+            Ablk.append(0.5 * (Aj + Aj.T))
         steps += 1
         # Every branch below is taken on values agreed by all ranks (a last-bit difference between
         # replicas must never let one rank leave the loop while the others enter the next
@@ -373,13 +407,16 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
             Bblk.append(R)
         if last or steps >= next_check:
             m = steps * b
-            T = np.zeros((m, m))
-            for j in range(steps):
-                T[j * b:(j + 1) * b, j * b:(j + 1) * b] = Ablk[j]
-                if j + 1 < steps:
-                    T[(j + 1) * b:(j + 2) * b, j * b:(j + 1) * b] = Bblk[j]
-                    T[j * b:(j + 1) * b, (j + 1) * b:(j + 2) * b] = Bblk[j].T
-            theta, Y = backend.dense_eig_top(T, neig)                 # Y: (neig, m)
+            if dev_blocks:
+                theta, Y = backend.projected_eig_top(A_dev, beta_dev, steps, neig)
+            else:
+                T = np.zeros((m, m))
+                for j in range(steps):
+                    T[j * b:(j + 1) * b, j * b:(j + 1) * b] = Ablk[j]
+                    if j + 1 < steps:
+                        T[(j + 1) * b:(j + 2) * b, j * b:(j + 1) * b] = Bblk[j]
+                        T[j * b:(j + 1) * b, (j + 1) * b:(j + 2) * b] = Bblk[j].T
+                theta, Y = backend.dense_eig_top(T, neig)             # Y: (neig, m)
             worst = 0.0
             if ok:
                 Ylast = _host(backend, Y[:, m - b:]).T                     # b x neig
@@ -400,6 +437,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
     if not converged:
         raise RuntimeError("eigen_krylov_dist: not converged within the subspace limit")
     dim = steps * b
+    _t0 = _t.perf_counter()
     Q = backend.mm(False, False, Ball[:dim], Y)                       # n x neig
     # The Ritz pairs of T are verified against K on the block that converges last (the smallest min(neig, b)
     # Ritz values: one more sharded product); only if the true residuals are not at the estimated level are all
@@ -423,6 +461,7 @@ def eigen_krylov_dist(backend, torch, dist, Kcols, n, rank, world, neig, eigtrun
         vals = np.asarray(hv[:neig], dtype=np.float64)
     lastkeeper = int(np.max(np.nonzero(vals >= eigtrunc * vals[0])[0])) + 1
     Qf = backend.mm(False, False, Q, Zr[:lastkeeper]) if refine else Q[:lastkeeper].contiguous()
+    _tick("Ritz vectors + verification", _t0)
     if _prof is not None and rank == 0:
         print("[bigkrls] eigen_krylov_dist steps=%d dim=%d" % (steps, dim), {kk: round(v, 3) for kk, v in _prof.items()}, flush=True)
     return vals, lastkeeper, Qf, backend.from_numpy(vals[:, None])

@@ -220,13 +220,22 @@ int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* str
 int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals,
                              int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
                              int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
+/* p[0 .. count) (device) = uniform values in [-0.5, 0.5) that depend on the element index and the seed only: the
+ * start block of the block Lanczos, the same on every rank (seed 20240229 is the single-GPU library's). */
+int bigkrls_dev_fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed);
 /* Orthonormalise the columns of the n x b block W (device, column-major, ld n; b <= 128) by Cholesky-QR applied
  * twice, in place; tmp: device scratch of the same size. h_R (host, b x b column-major) receives the upper
  * triangular R with W_in = W_out R, *h_breakdown is 1 when the Gram matrix was not positive definite (W is then
- * undefined). The block Lanczos step of the row-block path (bigkrls_amd/dist.py) calls it on the replicated block;
- * the reference has no counterpart (its Neig < N branch is arma::eigs_sym, src/eigen.cpp:18-22). */
+ * undefined); d_R (device, b x b, may be NULL) receives the same R. The block Lanczos step of the row-block path
+ * (bigkrls_amd/dist.py) calls it on the replicated block; the reference has no counterpart (its Neig < N branch is
+ * arma::eigs_sym, src/eigen.cpp:18-22). */
 int bigkrls_dev_cholqr2(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int64_t b, double* h_R,
-                        int32_t* h_breakdown);
+                        int32_t* h_breakdown, double* d_R);
+/* d_T (device, m x m column-major, m = steps b) = the block-tridiagonal projected matrix of a block Lanczos run:
+ * diagonal blocks 0.5 (A_j + A_j') from d_A_blocks (steps blocks of b x b), sub-diagonal blocks beta_{j+1} (upper
+ * triangular) from d_beta_blocks (steps - 1 blocks are read), super-diagonal blocks their transposes. */
+int bigkrls_dev_lanczos_projected(bigkrls_ctx* ctx, const double* d_A_blocks, const double* d_beta_blocks,
+                                  int64_t steps, int64_t b, double* d_T);
 /* dst (m x n, ldd) = src (m x n, lds), both on the device */
 int bigkrls_dev_copy_matrix(bigkrls_ctx* ctx, const double* src, int64_t m, int64_t n, int64_t lds,
                             double* dst, int64_t ldd);
