@@ -502,22 +502,39 @@ def eigen_dense_dist(backend, torch, dist, A, n, rank, world, nb, neig, eigtrunc
             dist.broadcast(strip, src=owner)
         return strip
 
+    import time as _t
+    _prof = {} if os.environ.get("BIGKRLS_VERBOSE") else None
+
+    def _tick(name, t0):
+        if _prof is not None:
+            backend.sync()
+            _prof[name] = _prof.get(name, 0.0) + (_t.perf_counter() - t0)
+        return _t.perf_counter()
+
     k = 0
     while has_panel(k):
         m = n - k - b
+        _t0 = _t.perf_counter()
         strip = bcast_strip(k, b)
+        _t0 = _tick("strip", _t0)
         backend.s1_panel(n, k, strip)
+        _t0 = _tick("panel QR + T", _t0)
         la0 = min(max(k + b - c0, 0), ncl)           # first own column inside the trailing matrix
         nact = ncl - la0
         backend.s1_av(n, k, A, la0, nact, Ysend)
+        _t0 = _tick("A22 V", _t0)
         if dist.is_initialized():
             dist.all_gather_into_tensor(Yrecv, Ysend)
             Yfull = Yrecv.view(world, b, nb).permute(1, 0, 2).reshape(b, world * nb)
         else:
             Yfull = Ysend
         Y = Yfull[:, k + b: n].contiguous()          # m x 64, column-major
+        _t0 = _tick("all-gather Y", _t0)
         backend.s1_update(n, k, Y, A, la0, nact, (c0 + la0) - (k + b) if nact > 0 else 0)
+        _t0 = _tick("thin products + update", _t0)
         k += b
+    if _prof is not None and rank == 0:
+        print("[bigkrls] eigen_dense_dist stage 1:", {kk: round(v, 3) for kk, v in _prof.items()}, flush=True)
     while k < n:                                      # what is left of the trailing matrix: not panels
         owner_end = min((k // nb + 1) * nb, n)
         w = min(b, owner_end - k)
