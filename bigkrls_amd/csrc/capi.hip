@@ -466,6 +466,22 @@ int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* str
   return dist_s1_put(ctx, n, k, strip, ncols);
 }
 
+int bigkrls_dev_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_panel_begin(ctx, n, k, strip);
+}
+
+int bigkrls_dev_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_thin(ctx, n, k, Y);
+}
+
+int bigkrls_dev_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                               int64_t row0) {
+  BK_TRY(check_ctx(ctx));
+  return dist_s1_update_cols(ctx, n, k, Acols, lda, ncols, row0);
+}
+
 int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals, int64_t n_vecs_max,
                              double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
                              int32_t part_index, int32_t part_count) {

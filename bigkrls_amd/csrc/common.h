@@ -243,6 +243,10 @@ int cholqr2_block(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int b, do
 // its diagonal blocks A_j (symmetrised) and sub-diagonal factors beta_{j+1} (upper triangular), b x b each
 int lanczos_projected(bigkrls_ctx* ctx, const double* d_A_blocks, const double* d_beta_blocks, int steps, int b,
                       double* d_T);
+int dist_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
+int dist_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y);
+int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                        int64_t row0);
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
 
 }  // namespace bk

@@ -2116,6 +2116,7 @@ static int eigen_retry_without_resident(bigkrls_ctx* ctx, const double* A, int64
 struct DistS1 {
   S1Ops ops;
   int n = 0;
+  bool panel_pending = false;   // a panel factorisation is running on the look-ahead stream (ev_join marks its end)
 };
 
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
@@ -2447,10 +2448,42 @@ int dist_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
   return BIGKRLS_OK;
 }
 
+// the panel factorisation and its T factor on the look-ahead stream, after everything queued on the main stream so
+// far; the next dist_s1_av / dist_s1_thin (which read V and T) wait for it
+int dist_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_REQUIRE(strip && k >= 0 && k % S2_B == 0 && ds->ops.has_panel((int)k), "s1_panel_begin: not a panel column");
+  BK_REQUIRE(!ds->panel_pending, "s1_panel_begin: the previous panel has not been consumed");
+  BK_TRY(side_stream_get(ctx));
+  hipStream_t side = ctx->side_stream, st = ctx->stream;
+  BK_HIP(hipEventRecord(ctx->ev_fork, st));
+  BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
+  double* W = ds->ops.W;
+  ctx->stream = side;
+  int rc = copy_matrix(ctx, strip, n - k, S2_B, n - k, W + k + k * n, n);
+  ctx->stream = st;
+  BK_TRY(rc);
+  BK_TRY(ds->ops.panel_qr((int)k, side));
+  BK_TRY(ds->ops.build_T((int)k, side));
+  BK_HIP(hipEventRecord(ctx->ev_join, side));
+  ds->panel_pending = true;
+  return BIGKRLS_OK;
+}
+
+static int dist_s1_wait_panel(bigkrls_ctx* ctx, DistS1* ds) {
+  if (ds->panel_pending) {
+    BK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    ds->panel_pending = false;
+  }
+  return BIGKRLS_OK;
+}
+
 int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda, int64_t ncols,
                double* Yout, int64_t ldy) {
   DistS1* ds = nullptr;
   BK_TRY(dist_state(ctx, n, &ds));
+  BK_TRY(dist_s1_wait_panel(ctx, ds));
   const int64_t m = n - k - S2_B;
   BK_REQUIRE(m > 0 && ncols >= 0 && (ncols == 0 || (Acols && Yout && lda >= m && ldy >= ncols)), "s1_av: bad arguments");
   if (ncols == 0) return BIGKRLS_OK;
@@ -2458,22 +2491,38 @@ int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int6
   return gemm(ctx, 1, 0, ncols, S2_B, m, 1.0, Acols, lda, ds->ops.ws.Vp, m, 0.0, Yout, ldy);
 }
 
-int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
-                   int64_t row0) {
+// the thin products of panel k from the gathered Y = A22 V: PZ1 = [V | Z], PZ2 = [Z | V]
+int dist_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_TRY(dist_s1_wait_panel(ctx, ds));
+  BK_REQUIRE(Y && n - k - S2_B > 0, "s1_thin: bad arguments");
+  return ds->ops.small_products((int)k, Y, nullptr);
+}
+
+// A22[:, cols] -= [V | Z] [Z | V][cols, :]' for `ncols` own columns whose first one is row `row0` of the trailing matrix
+int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                        int64_t row0) {
   DistS1* ds = nullptr;
   BK_TRY(dist_state(ctx, n, &ds));
   const int64_t m = n - k - S2_B;
-  BK_REQUIRE(Y && m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m, "s1_update: bad arguments");
-  BK_TRY(ds->ops.small_products((int)k, Y, nullptr));          // PZ1 = [V | Z], PZ2 = [Z | V]
+  BK_REQUIRE(m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m, "s1_update_cols: bad arguments");
   if (ncols == 0) return BIGKRLS_OK;
-  BK_REQUIRE(Acols && lda >= m, "s1_update: bad column block");
+  BK_REQUIRE(Acols && lda >= m, "s1_update_cols: bad column block");
   return gemm(ctx, 0, 1, m, ncols, 2 * S2_B, -1.0, ds->ops.ws.PZ1, m, ds->ops.ws.PZ2 + row0, m, 1.0, Acols, lda);
+}
+
+int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
+                   int64_t row0) {
+  BK_TRY(dist_s1_thin(ctx, n, k, Y));
+  return dist_s1_update_cols(ctx, n, k, Acols, lda, ncols, row0);
 }
 
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols) {
   DistS1* ds = nullptr;
   BK_TRY(dist_state(ctx, n, &ds));
   BK_REQUIRE(strip && k >= 0 && ncols > 0 && k + ncols <= n, "s1_put: bad arguments");
+  BK_TRY(dist_s1_wait_panel(ctx, ds));
   return copy_matrix(ctx, strip, n - k, ncols, n - k, ds->ops.W + k + k * n, n);
 }
 

@@ -196,6 +196,18 @@ class HipBackend:
     def s1_put(self, n, k, strip, ncols):
         _lib.call("bigkrls_dev_s1_put", self.ctx.handle, n, k, C.c_void_p(strip.data_ptr()), ncols)
 
+    def s1_panel_begin(self, n, k, strip):
+        """s1_panel on the look-ahead stream (returns at once; the next s1_av / s1_thin waits for it)."""
+        _lib.call("bigkrls_dev_s1_panel_begin", self.ctx.handle, n, k, C.c_void_p(strip.data_ptr()))
+
+    def s1_thin(self, n, k, Y):
+        _lib.call("bigkrls_dev_s1_thin", self.ctx.handle, n, k, C.c_void_p(Y.data_ptr()))
+
+    def s1_update_cols(self, n, k, A, la0, ncols, row0):
+        if ncols > 0:
+            _lib.call("bigkrls_dev_s1_update_cols", self.ctx.handle, n, k,
+                      C.c_void_p(A.data_ptr() + 8 * (la0 * n + k + S1_B)), n, ncols, row0)
+
     def eigen_resume(self, n, neig, eigtrunc, rank, world):
         """Stage 2, divide & conquer and this rank's slice of the back-transform. Returns (values
         host, lastkeeper, Q tensor (lastkeeper, n) whose rows outside the slice are zero, values tensor)."""
@@ -511,17 +523,20 @@ def eigen_dense_dist(backend, torch, dist, A, n, rank, world, nb, neig, eigtrunc
             _prof[name] = _prof.get(name, 0.0) + (_t.perf_counter() - t0)
         return _t.perf_counter()
 
+    # Look-ahead: the columns of the NEXT panel are updated first (by their owner), its strip is broadcast and its
+    # factorisation started on the look-ahead stream, and only then do the ranks update the rest of their columns --
+    # the latency-bound panel QR runs beside the throughput-bound update instead of after it.
     k = 0
+    if has_panel(0):
+        _t0 = _t.perf_counter()
+        backend.s1_panel(n, 0, bcast_strip(0, b))
+        _t0 = _tick("panel QR + T", _t0)
     while has_panel(k):
         m = n - k - b
         _t0 = _t.perf_counter()
-        strip = bcast_strip(k, b)
-        _t0 = _tick("strip", _t0)
-        backend.s1_panel(n, k, strip)
-        _t0 = _tick("panel QR + T", _t0)
         la0 = min(max(k + b - c0, 0), ncl)           # first own column inside the trailing matrix
         nact = ncl - la0
-        backend.s1_av(n, k, A, la0, nact, Ysend)
+        backend.s1_av(n, k, A, la0, nact, Ysend)     # (waits for the factorisation of panel k)
         _t0 = _tick("A22 V", _t0)
         if dist.is_initialized():
             dist.all_gather_into_tensor(Yrecv, Ysend)
@@ -530,8 +545,20 @@ def eigen_dense_dist(backend, torch, dist, A, n, rank, world, nb, neig, eigtrunc
             Yfull = Ysend
         Y = Yfull[:, k + b: n].contiguous()          # m x 64, column-major
         _t0 = _tick("all-gather Y", _t0)
-        backend.s1_update(n, k, Y, A, la0, nact, (c0 + la0) - (k + b) if nact > 0 else 0)
-        _t0 = _tick("thin products + update", _t0)
+        backend.s1_thin(n, k, Y)
+        row0 = (c0 + la0) - (k + b) if nact > 0 else 0
+        nxt = k + b
+        first = 0                                     # own columns already updated before the look-ahead
+        if has_panel(nxt):
+            if nxt // nb == rank:                     # the next panel's columns are the first active ones of their owner
+                first = min(b, nact)
+                backend.s1_update_cols(n, k, A, la0, first, row0)
+            _t0 = _tick("thin products + next panel's columns", _t0)
+            strip = bcast_strip(nxt, b)
+            _t0 = _tick("strip", _t0)
+            backend.s1_panel_begin(n, nxt, strip)
+        backend.s1_update_cols(n, k, A, la0 + first, nact - first, row0 + first)
+        _t0 = _tick("update (beside the next panel QR)", _t0)
         k += b
     if _prof is not None and rank == 0:
         print("[bigkrls] eigen_dense_dist stage 1:", {kk: round(v, 3) for kk, v in _prof.items()}, flush=True)

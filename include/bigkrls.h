@@ -217,6 +217,16 @@ int bigkrls_dev_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acol
 int bigkrls_dev_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda,
                           int64_t ncols, int64_t row0);
 int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
+/* Look-ahead form of the same step. bigkrls_dev_s1_update = bigkrls_dev_s1_thin (the thin products of panel k from
+ * the gathered Y) + bigkrls_dev_s1_update_cols (the update of `ncols` own columns starting at row `row0` of the
+ * trailing matrix). A rank calls s1_thin, updates the NEXT panel's columns first if it owns them, takes part in the
+ * broadcast of the next strip, starts the next panel's factorisation with bigkrls_dev_s1_panel_begin -- it runs on
+ * the context's look-ahead stream after everything queued so far and returns at once -- and then updates its
+ * remaining columns beside it; the next s1_av / s1_thin / s1_put waits for the factorisation. */
+int bigkrls_dev_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
+int bigkrls_dev_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y);
+int bigkrls_dev_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                               int64_t row0);
 int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals,
                              int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
                              int64_t* h_n_vecs, int32_t part_index, int32_t part_count);

@@ -97,15 +97,25 @@ class NumpyBackend:
             Acols = A.numpy()[la0:la0 + ncols, k + b:n]            # (ncols, m): own columns, transposed
             Ysend[:, la0:la0 + ncols] = torch.from_numpy((Acols @ self._V[k]).T.copy())
 
-    def s1_update(self, n, k, Y, A, la0, ncols, row0):
-        b = bkdist.S1_B
+    def s1_panel_begin(self, n, k, strip):          # (no streams on the host: the look-ahead call is the plain one)
+        self.s1_panel(n, k, strip)
+
+    def s1_thin(self, n, k, Y):
         V, T = self._V[k], self._T[k]
         Yt = Y.numpy().T @ T
         S = T.T @ (V.T @ Yt)
-        Z = Yt - 0.5 * V @ S
+        self._Z = Yt - 0.5 * V @ S
+
+    def s1_update_cols(self, n, k, A, la0, ncols, row0):
+        b = bkdist.S1_B
+        V, Z = self._V[k], self._Z
         if ncols > 0:
             An = A.numpy()
             An[la0:la0 + ncols, k + b:n] -= (V @ Z[row0:row0 + ncols].T + Z @ V[row0:row0 + ncols].T).T
+
+    def s1_update(self, n, k, Y, A, la0, ncols, row0):
+        self.s1_thin(n, k, Y)
+        self.s1_update_cols(n, k, A, la0, ncols, row0)
 
     def s1_put(self, n, k, strip, ncols):
         self._W[k:, k:k + ncols] = strip.numpy().T
