@@ -364,8 +364,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                         "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
                         "note": "achieved = algorithmic HBM bytes (band read once, 16 N b, + stored reflectors, "
                                 "4 N^2) / HIP-event duration. The band lives in LDS for the whole stage; the kernel "
-                                "is bound by the 2 message hops per sweep between neighbouring workgroups "
-                                "(N sweeps x ~4.4 us), not by HBM"}
+                                "is bound by the 2 message hops per sweep between neighbouring workgroups and the "
+                                "phases between an arrival and the next send (N sweeps x ~3.7 us), not by HBM"}
             return {"kernel": "bc_wavefront: one anti-diagonal wavefront of bulge-chasing tasks (stage 2 of the "
                               "two-stage tridiagonalisation, band b=64 -> tridiagonal), ~2N launches per fit",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
