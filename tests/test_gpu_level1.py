@@ -464,3 +464,65 @@ def test_eigen_large_panels_two_level_exchange(ctx):
     G = ops.gemm(True, False, Q, Q).to_numpy()
     assert np.max(np.abs(R)) / lam[0] < 1e-12
     assert np.max(np.abs(G - np.eye(k))) < 1e-11
+
+
+# --------------------------------------------------------------------------------------------
+# the device-side pieces of the block Lanczos that the row-block path drives through the C ABI
+# --------------------------------------------------------------------------------------------
+def test_dev_fill_random_is_a_function_of_index_and_seed(ctx):
+    from bigkrls_amd import _lib
+    a, b = ctx.empty(5000, 128), ctx.empty(5000, 128)
+    for m in (a, b):
+        _lib.call("bigkrls_dev_fill_random", ctx.handle, m.ptr, 5000 * 128, 20240229)
+    c = ctx.empty(5000, 128)
+    _lib.call("bigkrls_dev_fill_random", ctx.handle, c.ptr, 5000 * 128, 7)
+    ha, hb, hc = a.to_numpy(), b.to_numpy(), c.to_numpy()
+    assert np.array_equal(ha, hb) and not np.array_equal(ha, hc)
+    assert ha.min() >= -0.5 and ha.max() < 0.5 and abs(ha.mean()) < 2e-3
+    assert np.linalg.matrix_rank(ha[:300, :128]) == 128
+
+
+@pytest.mark.parametrize("n,b", [(5000, 128), (1237, 128), (4096, 64), (300, 17)])
+def test_dev_cholqr2_orthonormalises_and_reports_breakdown(ctx, n, b):
+    """W_in = W_out R with W_out'W_out = I to rounding and R upper triangular (Cholesky-QR twice, Gram product on
+    the MFMA GEMM, factorisation and inverse in the register-tile kernel); a pivot that is not positive sets the flag
+    (columns that are dependent only to rounding can slip through with a tiny positive pivot, as in any Cholesky)."""
+    from bigkrls_amd import _lib
+    rng = np.random.default_rng(n + b)
+    W0 = rng.standard_normal((n, b)) @ np.diag(np.logspace(0, -3, b)) + 0.05 * rng.standard_normal((n, 1))
+    W, tmp, Rd = ctx.from_numpy(F(W0)), ctx.empty(n, b), ctx.empty(b, b)
+    R = np.zeros((b, b), order="F")
+    brk = C.c_int32(-1)
+    _lib.call("bigkrls_dev_cholqr2", ctx.handle, W.ptr, tmp.ptr, n, b, R.ctypes.data_as(C.c_void_p), C.byref(brk), Rd.ptr)
+    Q = W.to_numpy()
+    assert brk.value == 0
+    assert np.abs(Q.T @ Q - np.eye(b)).max() < 1e-13
+    assert np.abs(np.tril(R, -1)).max() == 0.0 and np.all(np.diag(R) > 0)
+    assert np.abs(Q @ R - W0).max() < 1e-12 * np.abs(W0).max()
+    assert np.array_equal(Rd.to_numpy(), R)
+    W1 = W0.copy()
+    W1[:, b // 2] = 0.0                            # a zero column: the pivot is not positive
+    W = ctx.from_numpy(F(W1))
+    _lib.call("bigkrls_dev_cholqr2", ctx.handle, W.ptr, tmp.ptr, n, b, R.ctypes.data_as(C.c_void_p), C.byref(brk), None)
+    assert brk.value == 1
+
+
+def test_dev_lanczos_projected_assembles_the_block_tridiagonal_matrix(ctx):
+    from bigkrls_amd import _lib
+    rng = np.random.default_rng(3)
+    steps, b = 5, 32
+    A = rng.standard_normal((steps, b, b))
+    Bt = np.triu(rng.standard_normal((steps, b, b)))
+    # device layout: blocks one after the other, each column-major
+    Ad = ctx.from_numpy(F(np.concatenate([A[j].T.reshape(-1) for j in range(steps)])[:, None]))
+    Bd = ctx.from_numpy(F(np.concatenate([Bt[j].T.reshape(-1) for j in range(steps)])[:, None]))
+    m = steps * b
+    Td = ctx.empty(m, m)
+    _lib.call("bigkrls_dev_lanczos_projected", ctx.handle, Ad.ptr, Bd.ptr, steps, b, Td.ptr)
+    ref = np.zeros((m, m))
+    for j in range(steps):
+        ref[j * b:(j + 1) * b, j * b:(j + 1) * b] = 0.5 * (A[j] + A[j].T)
+        if j + 1 < steps:
+            ref[(j + 1) * b:(j + 2) * b, j * b:(j + 1) * b] = Bt[j]
+            ref[j * b:(j + 1) * b, (j + 1) * b:(j + 2) * b] = Bt[j].T
+    assert np.array_equal(Td.to_numpy(), ref)
