@@ -54,6 +54,12 @@ class BigKRLSPredicted(dict):
     r_class = "bigKRLS_predicted"
 
 
+class BigKRLSCV(dict):
+    """crossvalidate.bigKRLS's output (R/bigKRLS.R:1330-1336), class "bigKRLS_CV"."""
+
+    r_class = "bigKRLS_CV"
+
+
 def _as_host_matrix(X) -> np.ndarray:
     if is_device_matrix(X):
         return X.to_numpy()
@@ -85,7 +91,8 @@ def _call_native(name, *args):
 
 def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None, vcov_est=True,
             Neig=None, eigtrunc=None, lambda_=None, L=None, U=None, tol=None,
-            acf=False, noisy=None, ctx: Optional[Context] = None,
+            model_subfolder_name=None, overwrite_existing=False, Ncores=None,
+            acf=False, noisy=None, instructions=True, ctx: Optional[Context] = None,
             timings: Optional[Dict[str, float]] = None,
             trace: Optional[list] = None) -> BigKRLS:
     """Kernel-regularised least squares fit (R/bigKRLS.R:97-516).
@@ -94,14 +101,20 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     (R/bigKRLS.R:175-470) -- is ONE call into the C ABI, `bigkrls_fit` (include/bigkrls.h,
     csrc/fit.hip); this function checks the argument types, allocates the outputs (the reference's
     ownership rule: the caller allocates, native code writes in place) and assembles the list `w`.
-    `which_derivatives` is 1-based like R.  `lambda_` is R's `lambda`.  Persistence arguments
-    (model_subfolder_name, ...) and Ncores are out of scope.  `timings`
+    `which_derivatives` is 1-based like R.  `lambda_` is R's `lambda`.  `model_subfolder_name` /
+    `overwrite_existing` (R/bigKRLS.R:111-133, :471-504): the fitted object is also written to that
+    folder -- never silently into an existing one -- exactly as save_bigKRLS() does (device-resident
+    matrices as text, the rest as estimates.RData), and `w["path"]` records where.  `Ncores` (PSOCK
+    workers of the derivative loop, :337-363) and `instructions` are accepted and have no effect: the
+    marginal effects of all columns are one pass over K on the GPU.  `timings`
     (optional dict) receives per-phase seconds measured with HIP events on the context's stream;
     `trace` (optional list) the (lambda, Le) probes of the golden-section search.
     """
     ctx = ctx or default_context()
     if X is None or y is None:
         raise ValueError("y and X are required")
+    if model_subfolder_name is not None and not isinstance(model_subfolder_name, str):        # :112
+        raise TypeError("model_subfolder_name must be a character string")
     return_big_rectangles = is_device_matrix(X)                                  # :149
     # column-major like R / the C ABI
     Xh = np.array(_as_host_matrix(X), dtype=np.float64, order="F")
@@ -228,6 +241,9 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
         timings["native"] = t_native
         timings["wall"] = time.perf_counter() - t_wall0
     w["_ctx"] = ctx
+    if model_subfolder_name is not None:                                          # :471-504
+        from .persist import save_bigKRLS
+        save_bigKRLS(w, model_subfolder_name, overwrite_existing=overwrite_existing, noisy=noisy)
     return w
 
 
@@ -447,7 +463,7 @@ def _fold_contexts(ctx, devices):
 
 
 def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, folds=None,
-                  ctx: Optional[Context] = None, devices=None, **fit_args) -> Dict[str, object]:
+                  ctx: Optional[Context] = None, devices=None, **fit_args) -> BigKRLSCV:
     """crossvalidate.bigKRLS (R/bigKRLS.R:1146-1336).
 
     R partitions with set.seed(seed); sample() (:1168,1179,1232), a stream that
@@ -497,7 +513,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
             train_idx = rng.choice(N, Ntraining, replace=False)
         tr = np.asarray(train_idx)
         te = np.setdiff1d(np.arange(N), tr)
-        out = one_split(tr, te, contexts[0], _cv_fit, _cv_predict)
+        out = BigKRLSCV(one_split(tr, te, contexts[0], _cv_fit, _cv_predict))
         out.update(type="crossvalidated", seed=seed, ptesting=ptesting,
                    indices={"train.set": tr, "test.set": te})
         return out
@@ -510,7 +526,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
         folds = np.empty(N, dtype=int)
         folds[perm] = (np.arange(N) * Kfolds // N) + 1
     folds = np.asarray(folds)
-    out: Dict[str, object] = {"type": "KfoldsCV", "Kfolds": Kfolds, "seed": seed, "folds": folds}
+    out = BigKRLSCV({"type": "KfoldsCV", "Kfolds": Kfolds, "seed": seed, "folds": folds})
     keys = ["R2_is", "R2_oos", "MSE_is", "MSE_oos"]
     if marginals:
         keys += ["R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos"]

@@ -259,6 +259,18 @@ def test_save_load_round_trip(tmp_path, binary):
     assert np.array_equal(p0["predicted"], p1["predicted"]) and np.array_equal(p0["se.pred"], p1["se.pred"])
     again = bk.save_bigKRLS(out, str(tmp_path / "model"), noisy=False, binary=binary)   # existing folder is not reused
     assert again != folder and os.path.isdir(again)
+    assert os.path.exists(os.path.join(folder, "estimates.RData"))
+    if not binary:
+        # bigKRLS(..., model_subfolder_name=) saves as it goes (R/bigKRLS.R:111-133, :471-504); an existing folder
+        # is kept unless overwrite.existing
+        out2 = bk.bigKRLS(y, X, eigtrunc=0.01, model_subfolder_name=str(tmp_path / "model"), noisy=False)
+        assert out2["path"] == str(tmp_path / "model2") and os.path.exists(os.path.join(out2["path"], "K.txt"))
+        back2 = bk.load_bigKRLS(out2["path"], noisy=False)
+        assert np.array_equal(back2["coeffs"], out["coeffs"]) and back2["lambda"] == out["lambda"]
+        assert np.array_equal(back2["vcov.est.fitted"].to_numpy(), out["vcov.est.fitted"].to_numpy())
+        out3 = bk.bigKRLS(y, X, eigtrunc=0.01, model_subfolder_name=str(tmp_path / "model"), overwrite_existing=True,
+                          noisy=False)
+        assert out3["path"] == str(tmp_path / "model")
 
 
 @pytest.mark.gpu

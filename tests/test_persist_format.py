@@ -40,4 +40,7 @@ def test_writer_reproduces_the_fixture_byte_for_byte(tmp_path):
     assert len(lines) == 8 and lines[-1] == "" and all(len(l.split(",")) == 5 for l in lines[:-1])
     # a single column / single row keep their shape (read.big.matrix returns a matrix)
     write_big_matrix_text(M[:, :1], str(out))
-    assert read_big_matrix_text(str(out)).reshape(-1).tolist() == M[:, 0].tolist()
+    back = read_big_matrix_text(str(out))
+    assert back.shape == (7, 1) and back[:, 0].tolist() == M[:, 0].tolist()
+    write_big_matrix_text(M[:1, :], str(out))
+    assert read_big_matrix_text(str(out)).shape == (1, 5)
