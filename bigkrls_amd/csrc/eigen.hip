@@ -2002,10 +2002,12 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     dim = (int64_t)(steps + 1) * b;
   }
   if (getenv("BIGKRLS_VERBOSE")) fprintf(stderr, "[bigkrls] block Lanczos: n=%lld k=%lld steps=%d dim=%lld converged=%d\n", (long long)n, (long long)k, steps, (long long)dim, (int)converged);
+#ifdef BK_FAULT_INJECT
   {
-    const char* fault = getenv("BIGKRLS_FAULT");   // BIGKRLS_FAULT=noconv (tests): pretend the iteration stalled
+    const char* fault = getenv("BIGKRLS_FAULT");   // BIGKRLS_FAULT=noconv (test build): pretend the iteration stalled
     if (fault && std::string(fault) == "noconv") converged = false;
   }
+#endif
   if (!converged && dim < k) {
     set_error("eigen (Krylov): breakdown with a subspace smaller than the number of requested pairs");
     return BIGKRLS_ENOCONV;
@@ -2145,6 +2147,31 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // handed to the dense path in the same call -- A is untouched. Only an explicit
       // BIGKRLS_EIGK=krylov reports the non-convergence.
       if (rc != BIGKRLS_ENOCONV || mode == "krylov") return rc;
+      // ... provided its workspace fits: W, Q0, Q1, U = 4 n^2 doubles beside what the caller holds (320 GB at
+      // n = 100 000). Otherwise the non-convergence is the answer, with what the iteration saw.
+      {
+        size_t free_b = 0, total_b = 0;
+        BK_HIP(hipMemGetInfo(&free_b, &total_b));
+        int64_t held = 0;
+        for (int sl : {SLOT_EIG_A, SLOT_EIG_Q0, SLOT_EIG_Q1, SLOT_EIG_U}) held += std::min<int64_t>(ctx->ws_bytes[sl], n64 * n64 * 8);
+        // the Krylov workspace is released first if that is what it takes
+        int64_t kry = 0;
+        for (int sl : {SLOT_KRY_B, SLOT_KRY_W, SLOT_KRY_T, SLOT_KRY_Y}) kry += ctx->ws_bytes[sl];
+        const double need = 4.0 * 8.0 * (double)n64 * (double)n64 * 1.02 - (double)held;
+        if (need > (double)free_b + (double)kry) {
+          char buf[256];
+          snprintf(buf, sizeof buf,
+                   "eigen: the block Lanczos did not converge within its subspace limit and the dense fallback does "
+                   "not fit (needs %.1f GB more, %.1f GB free);", need / 1e9, ((double)free_b + (double)kry) / 1e9);
+          set_error(std::string(buf) + kry_diag);
+          return BIGKRLS_ENOCONV;
+        }
+        if (need > (double)free_b) {
+          for (int sl : {SLOT_KRY_B, SLOT_KRY_W, SLOT_KRY_T, SLOT_KRY_Y}) {
+            if (ctx->ws[sl]) { BK_HIP(hipStreamSynchronize(ctx->stream)); BK_HIP(hipFree(ctx->ws[sl])); ctx->ws[sl] = nullptr; ctx->ws_bytes[sl] = 0; }
+          }
+        }
+      }
       if (getenv("BIGKRLS_VERBOSE"))
         fprintf(stderr, "[bigkrls] block Lanczos did not converge: dense path;%s\n", kry_diag.c_str());
     }
@@ -2262,9 +2289,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       PinnedFetch pf1(ctx, 1);
       BK_TRY(pf1.add(&h_err1, s1.err, sizeof(int)));
       BK_TRY(pf1.finish());
-      // BIGKRLS_FAULT=watchdog (tests): pretend the watchdog fired on the first attempt
+#ifdef BK_FAULT_INJECT
+      // BIGKRLS_FAULT=watchdog (test build): pretend the watchdog fired on the first attempt
       const char* fault = getenv("BIGKRLS_FAULT");
       if (fault && std::string(fault) == "watchdog" && !ctx->no_resident) h_err1 = 1;
+#endif
       if (h_err1 != 0 && mode == EIG_RESUME) {
         set_error("eigen: watchdog of the register-resident panel QR fired during the distributed stage 1; "
                   "rerun with BIGKRLS_PQ=steps");

@@ -358,7 +358,8 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
     out->R2AME = c_ame * c_ame;
     // rescale: D *= sd(y); column i /= X.init.sd[i] -- index i, not which.derivatives[i] (:394-397, quirk Q6)
     for (int64_t i = 0; i < pd; ++i) {
-      const double f = x_sd[i];
+      // (which.derivatives may repeat columns, so pd can exceed p: X.init.sd[i] is then NA in R)
+      const double f = i < p ? x_sd[i] : NaN;
       double* col = D.data() + (size_t)i * n;
       long double s = 0.0L;
       for (int64_t r = 0; r < n; ++r) {

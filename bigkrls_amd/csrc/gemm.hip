@@ -563,9 +563,23 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void syrk_lower_kernel(GemmOperands g
 // segments too): C stays a fully stored, exactly symmetric matrix at half the MFMA work of a
 // full GEMM update. Used by the band reduction, whose next step is the plain product A22 V.
 // ACCUM = false: C = alpha A B' (nothing of C is read): the N x N variance matrices Q diag(w) Q' of the fit.
+// Tile order of the mirrored rank-k update. R == 0: column by column from tile t_off (consecutive workgroups =
+// consecutive XCDs take consecutive row tiles of one tile column, so every XCD streams the whole A operand through
+// its L2 once per tile column). R > 0: XCD-aware, L2-blocked: the tiles of the BN-wide columns [c0, c1) are ordered
+// band by band (a band = R consecutive 128-row tiles), inside a band column by column, and every XCD takes a
+// contiguous eighth of that sequence (xcd_remap): an XCD keeps the R row panels of A of its band in its L2 and
+// walks the columns, so each panel of B is fetched once per band instead of each panel of A once per column.
+struct SyrkMap {
+  int tiles;            // 128-row tiles of the matrix
+  int c0, c1;           // BN-wide tile columns of this launch
+  int R, nband, band0;  // rows per band, number of bands, first band (absolute index)
+  int t_off;            // R == 0 only
+  int band_start[160];  // band b (relative) starts at sequence index band_start[b]; [nband] = number of tiles
+};
+
 template <int BN, bool ACCUM = true>
 __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_kernel(
-    GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, int tiles, int t_off) {
+    GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, SyrkMap map) {
   // Tiles are 128 x BN. BN = 64 halves the accumulators so that THREE workgroups fit a CU: the
   // MFMA loop (8 k-tiles at k = 128) and the read-modify-write epilogue of one workgroup are
   // both latency-bound, and with identical tiles two co-resident workgroups run them in
@@ -573,16 +587,42 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NJ = BN / 32;
   constexpr int CPT = 128 / BN;   // tile columns per 128-wide column pair
-  const int t = blockIdx.x + t_off;
-  // lower-triangular tiles, column by column; columns come in groups of CPT that share their
-  // first row tile p: group p has CPT * (tiles - p) tiles and starts at CPT * (p tiles - p(p-1)/2)
-  int p = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t / CPT)) * 0.5);
-  auto gstart = [&](int q) { return CPT * (q * tiles - q * (q - 1) / 2); };
-  while (p > 0 && gstart(p) > t) --p;
-  while (gstart(p + 1) <= t) ++p;
-  const int rem = t - gstart(p);
-  const int tc = CPT * p + rem / (tiles - p);          // tile column (BN wide)
-  const int tm = p + rem % (tiles - p);                // tile row (128 high)
+  const int tiles = map.tiles;
+  int tc, tm, p;
+  if (map.R == 0) {
+    const int t = blockIdx.x + map.t_off;
+    // lower-triangular tiles, column by column; columns come in groups of CPT that share their
+    // first row tile p: group p has CPT * (tiles - p) tiles and starts at CPT * (p tiles - p(p-1)/2)
+    p = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * t / CPT)) * 0.5);
+    auto gstart = [&](int q) { return CPT * (q * tiles - q * (q - 1) / 2); };
+    while (p > 0 && gstart(p) > t) --p;
+    while (gstart(p + 1) <= t) ++p;
+    const int rem = t - gstart(p);
+    tc = CPT * p + rem / (tiles - p);          // tile column (BN wide)
+    tm = p + rem % (tiles - p);                // tile row (128 high)
+  } else {
+    const int sq = xcd_remap(blockIdx.x, gridDim.x);
+    int lo = 0, hi = map.nband;                // band_start[lo] <= sq < band_start[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (map.band_start[mid] <= sq) lo = mid; else hi = mid;
+    }
+    int sp = sq - map.band_start[lo];
+    const int r0 = (map.band0 + lo) * map.R, r1 = min(r0 + map.R, tiles);
+    // columns whose diagonal tile lies at or above r0 hold all r1 - r0 rows of the band ...
+    const int cfull = max(min(map.c1, CPT * (r0 + 1)), map.c0);
+    const int nfull = (cfull - map.c0) * (r1 - r0);
+    if (sp < nfull) {
+      tc = map.c0 + sp / (r1 - r0);
+      tm = r0 + sp % (r1 - r0);
+    } else {   // ... the columns through the band's diagonal corner hold the rows from their diagonal tile down
+      sp -= nfull;
+      tc = cfull;
+      while (sp >= r1 - tc / CPT) { sp -= r1 - tc / CPT; ++tc; }
+      tm = tc / CPT + sp;
+    }
+    p = tc / CPT;
+  }
   const int m0 = tm * BM, n0 = tc * BN;
   d4 acc[4][NJ];
   gemm_tile<false, true, BN>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
@@ -675,20 +715,53 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   }
 }
 
+// Host side of SyrkMap: the BN-wide columns [c0, c1) of the lower tile triangle (tile rows from the diagonal down).
+// rows_per_band == 0: the column-by-column order (development switch BIGKRLS_SYRK_ORDER=cols).
 template <int SBN>
-static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, double* C, int64_t ldc,
-                              int tiles, int tn_begin, int tn_end, bool skip_first_column = false) {
+static int64_t syrk_map_build(SyrkMap& mp, int tiles, int c0, int c1, int k) {
   constexpr int CPT = 128 / SBN;
-  // tile columns of one 128-wide group q share the first row tile q: the group starts at
-  // CPT * (q tiles - q(q-1)/2)
-  auto first_of = [&](int64_t q) { return CPT * (q * tiles - q * (q - 1) / 2); };
-  // (skip_first_column: the first SBN-wide tile column of group tn_begin, tiles - tn_begin tiles, was
-  //  updated by the caller)
-  const int64_t t0 = first_of(tn_begin) + (skip_first_column ? tiles - tn_begin : 0), nt = first_of(tn_end) - t0;
+  mp.tiles = tiles; mp.c0 = c0; mp.c1 = c1; mp.t_off = 0; mp.nband = 0; mp.band0 = 0;
+  static const int order_cols = [] { const char* e = getenv("BIGKRLS_SYRK_ORDER"); return e && std::string(e) == "cols"; }();
+  static const int r_env = [] { const char* e = getenv("BIGKRLS_SYRK_R"); return e ? atoi(e) : 0; }();
+  auto col_first = [&](int64_t c) -> int64_t {   // column-major index of the first tile of BN-wide column c
+    const int64_t q = c / CPT;
+    if (q >= tiles) return CPT * ((int64_t)tiles * tiles - (int64_t)tiles * (tiles - 1) / 2);
+    return CPT * (q * tiles - q * (q - 1) / 2) + (c % CPT) * (tiles - q);
+  };
+  const int64_t nt = col_first(c1) - col_first(c0);
+  if (order_cols || nt <= 0) {
+    mp.R = 0;
+    mp.t_off = (int)col_first(c0);
+    return nt;
+  }
+  // rows per band: the band's A panels (R x 128 x k doubles) take about 2 MB of the XCD's 4 MB L2
+  int R = r_env > 0 ? r_env : (int)std::min<int64_t>(32, std::max<int64_t>(2, (2 << 20) / ((int64_t)128 * 8 * std::max(k, 1))));
+  const int first_row = c0 / CPT;
+  while ((tiles - first_row + R - 1) / R > 159) ++R;
+  mp.R = R;
+  mp.band0 = first_row / R;
+  int64_t acc = 0;
+  int nb = 0;
+  for (int b = mp.band0; b * R < tiles; ++b, ++nb) {
+    mp.band_start[nb] = (int)acc;
+    const int r0 = b * R, r1 = std::min(r0 + R, tiles);
+    for (int tm = r0; tm < r1; ++tm) acc += std::max(0, std::min(c1, CPT * (tm + 1)) - c0);
+  }
+  mp.band_start[nb] = (int)acc;
+  mp.nband = nb;
+  return acc;   // == nt
+}
+
+template <int SBN, bool ACCUM>
+static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, double* C, int64_t ldc,
+                              int tiles, int c0, int c1) {
+  if (c0 >= c1) return BIGKRLS_OK;
+  SyrkMap mp;
+  const int64_t nt = syrk_map_build<SBN>(mp, tiles, c0, c1, g.K);
   if (nt <= 0) return BIGKRLS_OK;
-  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN>, smem_bytes(SBN)));
-  hipLaunchKernelGGL(syrk_mirror_kernel<SBN>, dim3((unsigned)nt), dim3(NT), smem_bytes(SBN), ctx->stream, g,
-                     alpha, C, ldc, tiles, (int)t0);
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN, ACCUM>, smem_bytes(SBN)));
+  hipLaunchKernelGGL((syrk_mirror_kernel<SBN, ACCUM>), dim3((unsigned)nt), dim3(NT), smem_bytes(SBN), ctx->stream, g,
+                     alpha, C, ldc, mp);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
 }
@@ -705,8 +778,10 @@ int syrk_mirror(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const doub
   // 128 x 64 tiles (three workgroups per CU) share the GPU better with a concurrent
   // register-resident panel QR; alone, 128 x 128 tiles are ~6 % faster (N = 20 000: 1.65 vs 1.76 ms)
   BK_REQUIRE(!skip_first_column || narrow_tiles, "syrk_mirror: skip_first_column needs 64-wide tiles");
-  if (narrow_tiles) return launch_syrk_mirror<64>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end, skip_first_column);
-  return launch_syrk_mirror<128>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
+  // (skip_first_column: the first 64-wide tile column of group tn_begin was updated by the caller)
+  if (narrow_tiles)
+    return launch_syrk_mirror<64, true>(ctx, g, alpha, C, ldc, tiles, 2 * tn_begin + (skip_first_column ? 1 : 0), 2 * tn_end);
+  return launch_syrk_mirror<128, true>(ctx, g, alpha, C, ldc, tiles, tn_begin, tn_end);
 }
 
 // C = alpha A B' for a product that is symmetric (A = Q diag(w), B = Q): lower tiles computed, stored twice
@@ -716,41 +791,22 @@ int syrk_mirror_set(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const 
   BK_REQUIRE(k > 0 && m < (1ll << 31) && k < (1ll << 31), "syrk_mirror_set: bad dimensions");
   GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
   const int tiles = (int)((m + BM - 1) / BM);
-  const int64_t nt = (int64_t)tiles * (tiles + 1) / 2;
-  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<128, false>, smem_bytes(128)));
-  hipLaunchKernelGGL((syrk_mirror_kernel<128, false>), dim3((unsigned)nt), dim3(NT), smem_bytes(128), ctx->stream, g,
-                     alpha, C, ldc, tiles, 0);
-  BK_CHECK_LAUNCH();
-  return BIGKRLS_OK;
+  return launch_syrk_mirror<128, false>(ctx, g, alpha, C, ldc, tiles, 0, tiles);
 }
 
 // 128 x 64 tiles, columns [c64_begin, c64_end) in units of 64: the lower triangle (with the
-// diagonal) of exactly those columns is updated and mirrored. Tiles are ordered by 128-wide column
-// group, inside a group first all tiles of its first 64-wide column, then those of the second.
+// diagonal) of exactly those columns is updated and mirrored.
 int syrk_mirror_cols(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double* C, int64_t ldc, int c64_begin, int c64_end) {
   if (m <= 0 || k <= 0) return BIGKRLS_OK;
   BK_REQUIRE(m < (1ll << 31) && k < (1ll << 31), "syrk_mirror_cols: dimension too large");
   GemmOperands g{A, B, lda, ldb, (int)m, (int)m, (int)k, nullptr};
   const int tiles = (int)((m + BM - 1) / BM);
-  const int ncol64 = (int)((m + 63) / 64);
-  if (c64_end < 0 || c64_end > ncol64) c64_end = ncol64;
-  if (c64_begin < 0) c64_begin = 0;
-  if (c64_begin >= c64_end) return BIGKRLS_OK;
-  auto tile_index = [&](int c64) -> int64_t {     // index of the first tile of 64-wide column c64
-    const int64_t q = c64 / 2;
-    if (q >= tiles) return 2 * ((int64_t)tiles * tiles - (int64_t)tiles * (tiles - 1) / 2);
-    return 2 * (q * tiles - q * (q - 1) / 2) + ((c64 & 1) ? tiles - q : 0);
-  };
   // (an odd last column of the matrix: the second column of the last group does not exist, but its
   //  tiles are enumerated; they lie entirely outside the matrix and store nothing)
-  const int64_t t0 = tile_index(c64_begin), nt = tile_index(c64_end == ncol64 ? 2 * tiles : c64_end) - t0;
-  if (nt <= 0) return BIGKRLS_OK;
-  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<64>, smem_bytes(64)));
-  hipLaunchKernelGGL(syrk_mirror_kernel<64>, dim3((unsigned)nt), dim3(NT), smem_bytes(64), ctx->stream, g,
-                     alpha, C, ldc, tiles, (int)t0);
-  BK_CHECK_LAUNCH();
-  return BIGKRLS_OK;
+  if (c64_end < 0 || c64_end > 2 * tiles) c64_end = 2 * tiles;
+  if (c64_begin < 0) c64_begin = 0;
+  return launch_syrk_mirror<64, true>(ctx, g, alpha, C, ldc, tiles, c64_begin, c64_end);
 }
 
 int syrk_lower(bigkrls_ctx* ctx, int64_t m, int64_t k, double alpha, const double* A, int64_t lda,
