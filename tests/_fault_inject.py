@@ -1,0 +1,53 @@
+"""The in-call recovery paths of the eigensolver, driven by the fault-injection hooks of the TEST build of the
+library (tests/capi/libbigkrls_hip_fault.so, -DBK_FAULT_INJECT; the shipped library has no such hooks).
+Run as a script by tests/test_gpu_configs.py: the library path is per process.
+BIGKRLS_FAULT=watchdog: the first attempt reports a fired persistent-kernel watchdog after stage 1; the call must
+redo the decomposition with the per-step kernels and succeed. BIGKRLS_FAULT=noconv: the block Lanczos reports
+non-convergence; the same call must fall through to the dense path (no user-visible switch, like the reference's
+eigs_sym branch, src/eigen.cpp:18-22)."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import numpy as np
+
+import bigkrls_amd._lib as L
+L.LIB_PATH = os.path.join(HERE, "capi", "libbigkrls_hip_fault.so")
+import bigkrls_amd as bk
+from bigkrls_amd import ops
+from bigkrls_amd.synth import synth
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def quality(K, vectors, values):
+    Kh, Q = K.to_numpy(), vectors.to_numpy()
+    d = np.asarray(values)[:Q.shape[1]]
+    return (float(np.max(np.abs(Kh @ Q - Q * d)) / abs(d[0])), float(np.max(np.abs(Q.T @ Q - np.eye(Q.shape[1])))))
+
+
+ctx = bk.Context(0)
+n, p = 3000, 5
+X, _ = synth(n, p, 9)
+K = ops.bGaussKernel(ctx.from_numpy((X - X.mean(0)) / X.std(0, ddof=1)), float(p))
+good = ops.bEigen(K, 40, -1.0)
+os.environ["BIGKRLS_FAULT"] = "watchdog"
+again = ops.bEigen(K, 40, -1.0)
+assert rel(again.values, good.values) < 1e-12
+res, orth = quality(K, again.vectors, again.values)
+assert res < 1e-11 and orth < 1e-11, (res, orth)
+os.environ["BIGKRLS_FAULT"] = "noconv"
+n2 = 16384                                                   # the size at which Lanczos is chosen by default
+X2, _ = synth(n2, p, 10)
+K2 = ops.bGaussKernel(ctx.from_numpy((X2 - X2.mean(0)) / X2.std(0, ddof=1)), float(p))
+fb = ops.bEigen(K2, 64, -1.0)
+del os.environ["BIGKRLS_FAULT"]
+kr = ops.bEigen(K2, 64, -1.0)
+assert rel(fb.values, kr.values) < 1e-10
+res, orth = quality(K2, fb.vectors, fb.values)
+assert res < 1e-11 and orth < 1e-11, (res, orth)
+print("fault injection OK")

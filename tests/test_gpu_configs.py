@@ -324,32 +324,15 @@ def test_c5_fit_properties_which_derivatives(ctx, monkeypatch):
 # --------------------------------------------------------------------------------------------
 # in-process recovery paths of the eigensolver
 # --------------------------------------------------------------------------------------------
-def test_eigen_watchdog_retry_and_lanczos_fallback(ctx, monkeypatch):
-    """BIGKRLS_FAULT=watchdog: the first attempt reports a fired persistent-kernel watchdog after
-    stage 1; the call must redo the decomposition with the per-step kernels and succeed.
-    BIGKRLS_FAULT=noconv: the block Lanczos reports non-convergence; the same call must fall through
-    to the dense path (no user-visible switch, like the reference's eigs_sym branch)."""
-    from bigkrls_amd import ops
-    n, p = 3000, 5
-    X, _ = orc.synth(n, p, 9)
-    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
-    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
-    good = ops.bEigen(K, 40, -1.0)
-    monkeypatch.setenv("BIGKRLS_FAULT", "watchdog")
-    again = ops.bEigen(K, 40, -1.0)
-    assert rel(again.values, good.values) < 1e-12
-    res, orth = eigen_quality(ops, K, again.vectors, again.values)
-    assert res < 1e-11 and orth < 1e-11
-    monkeypatch.setenv("BIGKRLS_FAULT", "noconv")
-    n2 = 16384                                                   # the size at which Lanczos is chosen by default
-    X2, _ = orc.synth(n2, p, 10)
-    K2 = ops.bGaussKernel(ctx.from_numpy((X2 - X2.mean(0)) / X2.std(0, ddof=1)), float(p))
-    fb = ops.bEigen(K2, 64, -1.0)
-    monkeypatch.delenv("BIGKRLS_FAULT")
-    kr = ops.bEigen(K2, 64, -1.0)
-    assert rel(fb.values, kr.values) < 1e-10
-    res, orth = eigen_quality(ops, K2, fb.vectors, fb.values)
-    assert res < 1e-11 and orth < 1e-11
+def test_eigen_watchdog_retry_and_lanczos_fallback():
+    """The recovery paths inside one eigen call (a fired watchdog -> per-step kernels; a block Lanczos that does not
+    converge -> dense path), driven through the fault-injection hooks of the TEST build of the library in a process
+    of its own (tests/_fault_inject.py); the shipped library carries no such hooks."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_fault_inject.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fault injection OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_lanczos_sampled_verification_matches_full_rayleigh_ritz(ctx, monkeypatch):

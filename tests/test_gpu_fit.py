@@ -78,6 +78,15 @@ def test_fit_which_derivatives_q6(ctx):
     out = bk.bigKRLS(y, X, which_derivatives=[2, 4], ctx=ctx)
     assert out["derivatives"].shape == (300, 2)
     assert_fit_parity(out, ref)
+    # a which.derivatives list longer than ncol(X) (repeats are legal in R): X.init.sd[i] is NA for i > p
+    # (R/bigKRLS.R:395-397), the standardised derivatives and the correctly subset variances stay finite
+    X2, y2 = orc.synth(200, 2, 45)
+    rep = bk.bigKRLS(y2, X2, which_derivatives=[1, 1, 2], ctx=ctx)
+    one = bk.bigKRLS(y2, X2, ctx=ctx)
+    assert rep["derivatives"].shape == (200, 3) and np.isnan(rep["derivatives"][:, 2]).all()
+    assert np.isnan(rep["avgderivatives"][0, 2]) and np.isfinite(rep["derivatives"][:, :2]).all()
+    assert np.allclose(rep["derivatives.std"][:, [0, 2]], one["derivatives.std"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(rep["var.avgderivatives"][0, [1, 2]], one["var.avgderivatives"][0], rtol=1e-8)
 
 
 def test_fit_user_lambda_and_no_derivative(ctx):

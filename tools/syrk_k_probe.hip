@@ -30,15 +30,29 @@ int main(int argc, char** argv) {
            name, (long long)m, k, narrow ? "128x64 " : "128x128", tn0, tn1, ms * 1e3,
            (double)m * (m + 1) * k / (ms * 1e-3) / 1e12, ms * 1e3 * 128.0 / k);
   };
+  auto timecols = [&](const char* name, int64_t m, int k, int c0, int c1) {
+    auto fn = [&] { syrk_mirror_cols(ctx, m, k, -1.0, A, n, B, n, C, n, c0, c1); };
+    fn(); hipStreamSynchronize(st);
+    hipEventRecord(e0, st); const int reps = 4;
+    for (int r = 0; r < reps; ++r) fn();
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double ca = 64.0 * c0, cb = c1 < 0 ? (double)m : 64.0 * c1;
+    const double fl = 2.0 * k * ((cb - ca) * m - 0.5 * (cb * cb - ca * ca));
+    printf("%-22s m=%6lld k=%3d tiles=128x64  c64[%d,%d): %8.1f us  %6.2f TFLOP/s\n", name, (long long)m, k, c0, c1,
+           ms * 1e3, fl / (ms * 1e-3) / 1e12);
+  };
+  const bool quick = argc > 2;
   for (int64_t m : {n, (int64_t)(n * 0.7), n / 2}) {
     for (int k : {128, 256, 384, 512}) {
-      timeit("syrk_mirror", m, k, false, 0, -1);
+      if (!quick) timeit("syrk_mirror", m, k, false, 0, -1);
       timeit("syrk_mirror", m, k, true, 0, -1);
     }
-    // the two halves of a k = 256 update split by tile columns (equal areas: the right part starts at 1 - 1/sqrt 2)
-    const int ncol128 = (int)((m + 127) / 128), j1 = (int)(ncol128 * 0.2929);
-    timeit("left tile columns", m, 256, false, 0, j1);
-    timeit("right tile columns", m, 256, false, j1, -1);
+    // the two equal-area pieces of a k = 256 update as the fit launches them (64-wide columns, the right part
+    // starts at 1 - 1/sqrt 2 of the columns)
+    const int ncol64 = (int)((m + 63) / 64), j1 = (int)(ncol64 * 0.2929 + 0.5);
+    timecols("piece b (left cols)", m, 256, 0, j1);
+    timecols("piece a (right cols)", m, 256, j1, -1);
   }
   return 0;
 }
