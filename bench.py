@@ -103,9 +103,10 @@ def symv_traffic(alg_bytes_total, launches):
 def pmc_ratio(kernel):
     """traffic / algorithmic HBM bytes of a kernel from the rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction and calibration as described in the files):
-    profiles/r02/r02_traffic_pmc.json (the kernels of the current stage 1, keys matched by prefix),
-    else profiles/r01_traffic_pmc.json."""
-    for rel in (("profiles", "r02", "r02_traffic_pmc.json"), ("profiles", "r01_traffic_pmc.json")):
+    profiles/r03/r03_traffic_pmc.json (the trailing update in this round's tile order), then
+    profiles/r02/r02_traffic_pmc.json (A22 V), else profiles/r01_traffic_pmc.json; keys matched by prefix."""
+    for rel in (("profiles", "r03", "r03_traffic_pmc.json"), ("profiles", "r02", "r02_traffic_pmc.json"),
+                ("profiles", "r01_traffic_pmc.json")):
         try:
             d = json.load(open(os.path.join(ROOT, *rel)))
         except Exception:
@@ -167,23 +168,30 @@ class CpuBaseline:
         self.reader.join(timeout=5.0)
         ph = {d["phase"]: d for d in self.lines if "phase" in d}
         cores = ph.get("ready", {}).get("cores", os.cpu_count() or 1)
+        host_cpus = ph.get("ready", {}).get("cpu_count", os.cpu_count() or 1)
         small = ph.get("small")
         res = {"unit": "s per fit", "cores": int(cores), "kind": "port"}
         lit_keys = ["kernel", "eigen", "lambda", "coeffs", "vcov_c", "vcov_fitted", "derivatives"]
         if "done" in ph:
             d = ph["done"]
+            ex = [k for k in lit_keys if ph.get(k, {}).get("extrapolated")]
+            ex_s = sum(ph[k]["s"] for k in ex)
             res.update({
                 "value": d["literal_s"],
                 "extrapolated": True,
                 "efficient_port_s": d["efficient_s"],
                 "sample": (f"literal restatement of the reference at the bench size N={self.n}, P={self.p} "
-                           f"(BLAS/LAPACK threads = {cores}; hand loops single-threaded like the reference): kernel "
+                           f"(BLAS/LAPACK threads = {cores}: the thread cap of numpy/scipy's bundled OpenBLAS on this "
+                           f"{host_cpus}-CPU host; hand loops single-threaded like the reference): kernel "
                            "row loop, dsyevd and V in full; lambda search = one literal solveforc probe x "
                            f"{d['probes']} probes; V_yhat (4N^3) and one derivative column's L'VL (4N^3) on N/20 "
-                           f"columns x 20, the column then x P={self.p} (all three marked extrapolated); "
+                           f"columns x 20, the column then x P={self.p} (all three marked extrapolated: "
+                           f"{ex_s:.0f} s = {100.0 * ex_s / max(d['literal_s'], 1e-9):.0f} % of `value` is scaled from "
+                           "samples, efficient_port_s is measured in full); "
                            f"efficient_port_s = the O(N^2 K) identities in full at N={self.n}"),
                 "phases_s": {k: ph[k]["s"] for k in lit_keys if k in ph},
-                "extrapolated_phases": [k for k in lit_keys if ph.get(k, {}).get("extrapolated")],
+                "extrapolated_phases": ex, "extrapolated_share": round(ex_s / max(d["literal_s"], 1e-9), 3),
+                "host_cpus": int(host_cpus),
                 "efficient_phases_s": d["efficient_phases_s"],
                 "lastkeeper": d["lastkeeper"], "lambda": d["lam"],
             })
@@ -308,7 +316,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
 
     prof = {name: ctx.get_profile(name) for name in
             ("symv", "kernel_block", "trailing_update", "band_update", "band_update2", "band_av", "bulge_chase",
-             "panel_qr", "lanczos_kb", "lanczos_cgs2")}
+             "panel_qr", "lanczos_kb", "lanczos_cgs2", "solveforc_probe", "deriv_rows", "yhat_gemv", "vcov_syrk")}
     ctx.set_profile(False)
 
     res = None
@@ -396,6 +404,50 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                             "all-to-all exchanges of partial sums between its workgroups (~6-11 us each), and its "
                             "duration is hidden behind the trailing update it runs concurrently with"}
 
+        def hbm_entry(name, kernel, note, flops_per_byte=None):
+            ms, by, cnt = prof[name]
+            if ms <= 0:
+                return None
+            gbs = (by / 1e9) / (ms / 1e3)
+            e = {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches_sampled": cnt,
+                 "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2), "total_ms_per_fit": round(ms / args.steps, 3),
+                 "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0), "note": note}
+            if flops_per_byte:
+                e["tflops"] = round(gbs * flops_per_byte / 1e3, 2)
+            return e
+
+        n_probes_note = ("one probe of the golden-section search per launch; the launch first folds the previous probe's "
+                         "loss and takes R's branch on the device (no read-back inside the search)")
+        extra = [
+            hbm_entry("solveforc_probe", "sf_probe_kernel: one solveforc probe, c_i = sum_k Q_ik a_k/(d_k+lambda), "
+                      "g_i = sum_k Q_ik^2/(d_k+lambda), Le = sum (c_i/g_i)^2 (src/solveforc.cpp:13-65 in O(NK))",
+                      "achieved = 8 N K algorithmic bytes (Q read once per probe, K = lastkeeper) / HIP-event duration of "
+                      "one sampled probe launch; " + n_probes_note + "; Q (8 N K = "
+                      f"{8e-6 * n * int(lastkeeper):.0f} MB) stays in the Infinity Cache between probes", 0.5),
+            hbm_entry("deriv_rows", "deriv_rows: K [1, c, x_j, x_j o c | b_j, b_j o c] for all columns as one skinny fp64 "
+                      "MFMA GEMM (gemm_kernel<N,N,64>) + O(NP) finalize (src/bigderiv_v3.cpp:13-111 in O(N^2))",
+                      "achieved = 8 N^2 algorithmic bytes (K read once for ALL columns) / HIP-event duration of the whole "
+                      "pass (column min/max, operand build, GEMM, finalize)",
+                      (2.0 + 2.0 * (p if cfg["which"] is None else len(cfg["which"]))) / 4.0),
+            hbm_entry("yhat_gemv", "gemv_n: yfitted = K c over the full kernel (R/bigKRLS.R:291)",
+                      "achieved = 8 N^2 algorithmic bytes / HIP-event duration", 0.25),
+        ]
+        vms, vfl, vcnt = prof["vcov_syrk"]
+        if vms > 0:
+            vtf = vfl / (vms / 1e3) / 1e12
+            extra.append({"kernel": "syrk_mirror_kernel<128,false>: vcov.est.c / vcov.est.fitted = Q diag(w) Q' on the lower "
+                                    "tile triangle, stored twice (R/bigKRLS.R:299-307)",
+                          "bound": "mfma", "achieved": round(vtf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(vtf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_sampled": vcnt,
+                          "avg_launch_us": round(vms * 1e3 / max(vcnt, 1), 2),
+                          "total_ms_per_fit": round(vms / args.steps, 3),
+                          "hbm_write_gbs": round(8.0 * n * n / 1e9 / (vms / max(vcnt, 1) / 1e3), 1),
+                          "note": "achieved = N (N+1) K algorithmic flops per matrix (K = lastkeeper; the lower tiles are "
+                                  "computed, the mirror is stored) / HIP-event duration; at small K the launch is bound by "
+                                  "its 8 N^2 bytes of stores (hbm_write_gbs)"})
+        extra = [e for e in extra if e]
+
         cands = [
             symv_entry(),
             bulge_entry(),
@@ -406,7 +458,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "b = 64, m = trailing size minus the next panel's 64 columns, which the preceding fused "
                        "kernel s1_fused_z updates) / HIP-event duration on the launch stream; traffic = algorithmic "
                        "HBM bytes of the launch (read 4 m^2 + write 8 m^2) x the FETCH_SIZE+WRITE_SIZE / algorithmic "
-                       "ratio of profiles/r02/r02_traffic_pmc.json for the 128x64-tile variant (1.149)",
+                       "ratio of profiles/r03/r03_traffic_pmc.json for the 128x64 tiles in the XCD-aware band-major order (1.002; 1.149 in "
+                       "round 2's column order)",
                        traffic=(lambda flops: round(12.0 * flops / 128.0 * pmc_ratio("syrk_mirror_kernel<64> k=128"), 0))
                        if pmc_ratio("syrk_mirror_kernel<64> k=128") else None),
             mfma_entry("band_update2", "syrk_mirror_kernel<64> at k = 256: A22 -= [V Z V Z][Z V Z V]' for a GROUP of two "
@@ -415,7 +468,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "achieved = algorithmic flops of the piece's columns of the lower triangle, 2*256*sum_c (m - c), / "
                        "HIP-event duration on the launch stream; traffic = algorithmic HBM bytes of the piece (read 4 + write 8 "
                        "bytes per lower-triangle entry, mirrored: 12 bytes per 256 flops) x the FETCH_SIZE+WRITE_SIZE / "
-                       "algorithmic ratio measured for the two pieces (profiles/r02/r02_traffic_pmc.json, 1.194)",
+                       "algorithmic ratio measured for the two pieces (profiles/r03/r03_traffic_pmc.json, 1.014)",
                        traffic=(lambda flops: round(12.0 * flops / 256.0 * pmc_ratio("syrk_mirror_kernel<64> k=256, the two"), 0))
                        if pmc_ratio("syrk_mirror_kernel<64> k=256, the two") else None),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
@@ -506,7 +559,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                         "executes half of them and mirrors); for P <~ 40 the build is HBM-write bound (8 N^2 bytes, "
                         "AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
             "roofline": roof,
-            "other_kernels": [c for c in cands if c is not roof],
+            "other_kernels": [c for c in cands if c is not roof] + extra,
         }
         if tu_ms > 0:
             res["trailing_update"] = {"tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3), "launches": tu_n}

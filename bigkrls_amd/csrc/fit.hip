@@ -266,7 +266,9 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   // ---- step 4: coefficients, fitted values (:286-291) -----------------------------------------------
   double Le = 0.0;
   BK_TRY(solveforc(ctx, dQ, n, k, n, dvals, da, lambda, dc, &Le));
+  if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
   BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                              // yfitted = K c (full K)
+  if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
   std::vector<double> coeffs(n), yhat(n);
   BK_HIP(hipMemcpyAsync(pin, dc, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));        // dyhat follows dc
   BK_HIP(hipStreamSynchronize(st));
@@ -294,7 +296,9 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
+        if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
         BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_c, n));
+        if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_c
@@ -304,7 +308,9 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         for (int64_t i = 0; i < k; ++i) pin[i] = wv[i] * vals[i] * vals[i];
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
+        if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
         BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_fitted, n));
+        if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_fitted
@@ -335,7 +341,9 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
       }
     }
     BK_TRY(upload(ctx, dXe, pin, n * pd));
+    if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
     BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n));
+    if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
     BK_HIP(hipStreamSynchronize(st));
     std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
     BK_TRY(upload(ctx, dw, pin, k));

@@ -10,6 +10,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstring>
 #include <limits>
 
 namespace bk {
@@ -236,11 +237,177 @@ int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, doub
   return BIGKRLS_OK;
 }
 
+// ---- golden-section search as a device-resident loop ------------------------------------------------------
+// The search state lives in HBM; probe launch i first CONSUMES the loss of probe i-1 (every workgroup sums the
+// row blocks' partial losses in the same fixed order and takes the same branch of R's loop, workgroup 0 records
+// state and trace) and then evaluates the loss at the lambda that decision asks for. One launch per probe, no
+// read-back inside the search: the host enqueues a chain of launches, the ones behind the terminating decision
+// return at once, and state + trace come back in one copy. The arithmetic of the control step is R's, statement
+// for statement and without fused multiply-adds (R/bigKRLS_Rcpp_functions.R:38-77).
+struct SfState {
+  double L, U, X1, X2, S1, S2, tol, cur, lambda, last_le;
+  int pending;   // the slot (1 or 2) the probe at `cur` fills
+  int done;
+  int np;        // losses consumed so far (= probes completed)
+  int fresh;     // no probe is in flight: the next launch starts one without consuming (start / resumed chain)
+};
+
+__device__ __forceinline__ SfState sf_step(SfState s, double le) {
+  const double G = 0.381966;
+  s.last_le = le;
+  if (s.pending == 1) s.S1 = le; else s.S2 = le;
+  s.np += 1;
+  if (s.np == 1) {               // S1 <- loo(X1) done; S2 <- loo(X2) next (:40-41)
+    s.cur = s.X2;
+    s.pending = 2;
+    return s;
+  }
+  if (fabs(__dsub_rn(s.S1, s.S2)) > s.tol) {                       // while (abs(S1 - S2) > tol)  (:55)
+    if (s.S1 < s.S2) {                                            // :57-62
+      s.U = s.X2;
+      s.X2 = s.X1;
+      s.X1 = __dadd_rn(s.L, __dmul_rn(G, __dsub_rn(s.U, s.L)));
+      s.S2 = s.S1;
+      s.cur = s.X1;
+      s.pending = 1;
+    } else {                                                      // :66-71
+      s.L = s.X1;
+      s.X1 = s.X2;
+      s.X2 = __dsub_rn(s.U, __dmul_rn(G, __dsub_rn(s.U, s.L)));
+      s.S1 = s.S2;
+      s.cur = s.X2;
+      s.pending = 2;
+    }
+  } else {
+    s.done = 1;
+    s.lambda = (s.S1 < s.S2) ? s.X1 : s.X2;                       // :77
+  }
+  return s;
+}
+
+// sum of `n` partial losses in a fixed order, identical in every workgroup (256 threads)
+__device__ __forceinline__ double sf_block_total(const double* __restrict__ part, int n, double* sh) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum_sf(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// grid (row blocks of 256, splits over k). consume_only: the launch that closes a chain (one workgroup).
+__global__ __launch_bounds__(256) void sf_probe_kernel(int n_rows, int k, int k_per_split,
+                                                       const double* __restrict__ Q, int64_t ldq,
+                                                       const double* __restrict__ d, const double* __restrict__ a,
+                                                       const SfState* __restrict__ st_in, SfState* __restrict__ st_out,
+                                                       const double* __restrict__ le_in, double* __restrict__ le_out,
+                                                       int n_le, double* __restrict__ pc, double* __restrict__ pg,
+                                                       double* __restrict__ trace, int max_trace, int consume_only) {
+  __shared__ double sw[SF_KC];
+  __shared__ double swa[SF_KC];
+  __shared__ double sh[4];
+  SfState s = *st_in;
+  if (!s.done) {
+    if (!s.fresh) {
+      const double le = sf_block_total(le_in, n_le, sh);
+      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && trace != nullptr && s.np < max_trace) {
+        trace[2 * s.np] = s.cur;
+        trace[2 * s.np + 1] = le;
+      }
+      s = sf_step(s, le);
+    }
+    s.fresh = consume_only;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *st_out = s;
+  if (s.done || consume_only) return;
+  const double lambda = s.cur;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = min(k, kb + k_per_split);
+  double c0 = 0.0, c1 = 0.0, g0 = 0.0, g1 = 0.0;
+  for (int base = kb; base < ke; base += SF_KC) {
+    const int cnt = min(SF_KC, ke - base);
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+      const double wi = 1.0 / (d[base + threadIdx.x] + lambda);
+      sw[threadIdx.x] = wi;
+      swa[threadIdx.x] = a[base + threadIdx.x] * wi;
+    }
+    __syncthreads();
+    if (row < n_rows) {
+      const double* q = Q + row + (int64_t)base * ldq;
+      int j = 0;
+      // four eigenvector entries in flight per thread and pass
+      for (; j + 3 < cnt; j += 4) {
+        const double q0 = q[(int64_t)j * ldq], q1 = q[(int64_t)(j + 1) * ldq];
+        const double q2 = q[(int64_t)(j + 2) * ldq], q3 = q[(int64_t)(j + 3) * ldq];
+        c0 += q0 * swa[j];
+        g0 += q0 * q0 * sw[j];
+        c1 += q1 * swa[j + 1];
+        g1 += q1 * q1 * sw[j + 1];
+        c0 += q2 * swa[j + 2];
+        g0 += q2 * q2 * sw[j + 2];
+        c1 += q3 * swa[j + 3];
+        g1 += q3 * q3 * sw[j + 3];
+      }
+      for (; j < cnt; ++j) {
+        const double q0 = q[(int64_t)j * ldq];
+        c0 += q0 * swa[j];
+        g0 += q0 * q0 * sw[j];
+      }
+    }
+  }
+  if (gridDim.y > 1) {
+    if (row < n_rows) {
+      pc[(int64_t)blockIdx.y * n_rows + row] = c0 + c1;
+      pg[(int64_t)blockIdx.y * n_rows + row] = g0 + g1;
+    }
+    return;
+  }
+  double t = 0.0;
+  if (row < n_rows) {
+    const double r = (c0 + c1) / (g0 + g1);
+    t = r * r;
+  }
+  t = wave_sum_sf(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) le_out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// splits > 1: the row blocks' losses from the k-split partial sums (skipped once the search is done)
+__global__ __launch_bounds__(256) void sf_probe_finish_kernel(int n_rows, int splits, const double* __restrict__ pc,
+                                                              const double* __restrict__ pg,
+                                                              const SfState* __restrict__ st,
+                                                              double* __restrict__ le_part) {
+  __shared__ double sh[4];
+  if (st->done) return;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  double t = 0.0;
+  if (row < n_rows) {
+    double cs = 0.0, gs = 0.0;
+    for (int z = 0; z < splits; ++z) {
+      cs += pc[(int64_t)z * n_rows + row];
+      gs += pg[(int64_t)z * n_rows + row];
+    }
+    const double r = cs / gs;
+    t = r * r;
+  }
+  t = wave_sum_sf(t);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) le_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
                   const double* d, const double* a, const double* h_vals_all, int64_t n_vals,
                   double L, double U, double tol, double* h_lambda, int64_t* h_nprobes,
                   double* h_trace, int64_t max_trace) {
   BK_REQUIRE(h_lambda, "lambda_search: null output");
+  BK_REQUIRE(n > 0 && k > 0 && n < (1ll << 31) && k < (1ll << 31), "lambda_search: bad dimensions");
+  BK_REQUIRE(Q && d && a, "lambda_search: null pointer");
   if (tol <= 0.0) tol = 1e-3 * (double)n;  // R/bigKRLS_Rcpp_functions.R:11-12
   if (L < 0.0 || U < 0.0) {
     double l0, u0;
@@ -248,46 +415,84 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64
     if (L < 0.0) L = l0;
     if (U < 0.0) U = u0;
   }
-  int64_t np = 0;
-  int status = BIGKRLS_OK;
-  auto loo = [&](double lam) -> double {
-    double le = 0.0;
-    int s = solveforc(ctx, Q, n, k, ldq, d, a, lam, nullptr, &le);
-    if (s != BIGKRLS_OK) status = s;
-    if (h_trace && np < max_trace) {
-      h_trace[2 * np] = lam;
-      h_trace[2 * np + 1] = le;
-    }
-    ++np;
-    return le;
-  };
-  const double G = 0.381966;
-  double X1 = L + G * (U - L);
-  double X2 = U - G * (U - L);
-  double S1 = loo(X1);
-  double S2 = loo(X2);
-  while (status == BIGKRLS_OK && std::fabs(S1 - S2) > tol) {
-    if (S1 < S2) {
-      U = X2;
-      X2 = X1;
-      X1 = L + G * (U - L);
-      S2 = S1;
-      S1 = loo(X1);
-    } else {
-      L = X1;
-      X1 = X2;
-      X2 = U - G * (U - L);
-      S1 = S2;
-      S2 = loo(X2);
-    }
-    if (np > 10000) {
-      set_error("lambda_search: golden section did not terminate (NaN loss?)");
-      return BIGKRLS_ENOCONV;
-    }
+  hipStream_t st = ctx->stream;
+  const int rb = (int)((n + 255) / 256);
+  int splits = (1024 + rb - 1) / rb;
+  const int max_splits = (int)((k + SF_KC - 1) / SF_KC);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int kps = (int)(((k + splits - 1) / splits + SF_KC - 1) / SF_KC * SF_KC);
+  splits = (int)((k + kps - 1) / kps);
+  constexpr int CHAIN = 48;        // probe launches per chain (a search takes 15-40)
+  constexpr int DEV_TRACE = 512;   // probes recorded on the device
+  // workspace: state[2], le[2][rb], trace[2 DEV_TRACE], pc / pg [splits n]
+  const int64_t st_d = (2 * (int64_t)sizeof(SfState) + 7) / 8;
+  const int64_t nd = st_d + 2 * rb + 2 * DEV_TRACE + (splits > 1 ? 2 * (int64_t)splits * n : 0) + 8;
+  void* p = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_SOLVE_PART, nd * sizeof(double), &p));
+  SfState* dstate = (SfState*)p;
+  double* le = (double*)p + st_d;
+  double* dtrace = le + 2 * rb;
+  double* pc = dtrace + 2 * DEV_TRACE;
+  double* pg = pc + (splits > 1 ? (int64_t)splits * n : 0);
+  // initial state (:38-39): X1 <- L + .381966 (U - L); X2 <- U - .381966 (U - L)
+  double* hp = nullptr;
+  const int64_t hp_d = st_d + 2 * DEV_TRACE;
+  BK_TRY(pinned_get(ctx, hp_d, &hp));
+  SfState s0{};
+  {
+    const volatile double G = 0.381966;   // (volatile: no contraction of the two statements into FMAs)
+    const volatile double span = U - L;
+    const volatile double gs = G * span;
+    s0.L = L; s0.U = U;
+    s0.X1 = L + gs;
+    s0.X2 = U - gs;
   }
-  if (status != BIGKRLS_OK) return status;
-  *h_lambda = (S1 < S2) ? X1 : X2;
-  if (h_nprobes) *h_nprobes = np;
+  s0.tol = tol;
+  s0.cur = s0.X1;
+  s0.pending = 1;
+  s0.fresh = 1;
+  std::memcpy(hp, &s0, sizeof(SfState));
+  BK_HIP(hipMemcpyAsync(&dstate[0], hp, sizeof(SfState), hipMemcpyHostToDevice, st));
+  SfState fin{};
+  int launched = 0;
+  for (int chain = 0; chain < 256; ++chain) {
+    for (int i = 0; i <= CHAIN; ++i, ++launched) {
+      const int cur = launched & 1;
+      const bool close = (i == CHAIN);
+      const bool samp = ctx->profile && chain == 0 && i == 1;
+      if (samp) BK_TRY(prof_begin(ctx, "solveforc_probe", 8.0 * (double)n * (double)k));
+      hipLaunchKernelGGL(sf_probe_kernel, close ? dim3(1, 1) : dim3(rb, splits), dim3(256), 0, st, (int)n, (int)k, kps, Q, ldq,
+                         d, a, (const SfState*)&dstate[cur], &dstate[cur ^ 1], (const double*)(le + (cur ^ 1) * rb),
+                         le + cur * rb, rb, pc, pg, dtrace, DEV_TRACE, close ? 1 : 0);
+      if (samp) BK_TRY(prof_end(ctx, "solveforc_probe"));
+      BK_CHECK_LAUNCH();
+      if (!close && splits > 1) {
+        hipLaunchKernelGGL(sf_probe_finish_kernel, dim3(rb), dim3(256), 0, st, (int)n, splits, (const double*)pc,
+                           (const double*)pg, (const SfState*)&dstate[cur ^ 1], le + cur * rb);
+        BK_CHECK_LAUNCH();
+      }
+    }
+    // the closing launch consumed the chain's last loss without starting a probe: a search that is not done
+    // resumes from exactly that state with its next launch
+    BK_HIP(hipMemcpyAsync(hp, &dstate[launched & 1], sizeof(SfState), hipMemcpyDeviceToHost, st));
+    if (h_trace && max_trace > 0)   // (8 KB: cheaper than a second synchronisation once the search is known to be done)
+      BK_HIP(hipMemcpyAsync(hp + st_d, dtrace, (size_t)(2 * DEV_TRACE) * sizeof(double), hipMemcpyDeviceToHost, st));
+    BK_HIP(hipStreamSynchronize(st));
+    std::memcpy(&fin, hp, sizeof(SfState));
+    if (fin.done) break;
+    if (fin.np > 10000) break;   // (a NaN loss ends R's loop at once: abs(NaN) > tol is FALSE)
+  }
+  if (!fin.done) {
+    set_error("lambda_search: golden section did not terminate (NaN loss?)");
+    return BIGKRLS_ENOCONV;
+  }
+  *h_lambda = fin.lambda;
+  if (h_nprobes) *h_nprobes = fin.np;
+  if (h_trace && max_trace > 0) {
+    const int64_t cnt = std::min<int64_t>(std::min<int64_t>(fin.np, max_trace), DEV_TRACE);
+    std::memcpy(h_trace, hp + st_d, (size_t)(2 * cnt) * sizeof(double));
+  }
   return BIGKRLS_OK;
 }
 

@@ -30,6 +30,12 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+def unit_columns(n, rows):
+    E = np.zeros((n, len(rows)))
+    E[np.asarray(rows), np.arange(len(rows))] = 1.0
+    return E
+
+
 def standardized(X, y):
     return (X - X.mean(0)) / X.std(0, ddof=1), (y - y.mean()) / y.std(ddof=1)
 
@@ -121,6 +127,31 @@ def test_c2_full_fit_vs_oracle(ctx, eigtrunc):
         assert rel(out[key].to_numpy(), ref[key]) < TOL, key
 
 
+def test_c2_size_fit_with_a_binary_column_vs_oracle(ctx):
+    """A C2-size fit (N=5000, P=10) whose last column is binary (SURVEY 8(d)'s binary variant of G(N,P,seed);
+    threshold from examples/numeric_convergence.md:13): the first-difference branch of BigDerivMat
+    (src/bigderiv_v3.cpp:31-87) at a size where the derivative pass runs many tiles, against the oracle."""
+    import bigkrls_amd as bk
+    n, p = 5000, 10
+    X, y = orc.synth(n, p, 112, binary_last=True)
+    assert np.unique(X[:, -1]).size == 2
+    ref = orc.fit(y, X, literal=False)
+    out = bk.bigKRLS(y, X, ctx=ctx)
+    assert out["binaryindicator"].tolist() == [False] * (p - 1) + [True]
+    assert out["lastkeeper"] == ref["lastkeeper"]
+    assert abs(out["lambda"] - ref["lambda"]) <= TOL * ref["lambda"]
+    for key in ["coeffs", "yfitted", "derivatives", "avgderivatives", "var.avgderivatives",
+                "derivatives.std", "var.avgderivatives.std"]:
+        assert rel(out[key], ref[key]) < TOL, key
+    # the binary column by itself (its scale differs from the continuous ones')
+    assert rel(out["derivatives.std"][:, -1], ref["derivatives.std"][:, -1]) < TOL
+    assert abs(out["var.avgderivatives.std"][-1] - ref["var.avgderivatives.std"][-1]) <= TOL * ref["var.avgderivatives.std"][-1]
+    for key in ["R2", "R2AME", "Looe", "Neffective"]:
+        assert abs(out[key] - ref[key]) <= TOL * abs(ref[key]), key
+    for key in ["vcov.est.c", "vcov.est.fitted"]:
+        assert rel(out[key].to_numpy(), ref[key]) < TOL, key
+
+
 # --------------------------------------------------------------------------------------------
 # C3
 # --------------------------------------------------------------------------------------------
@@ -169,6 +200,31 @@ def test_c3_eigen_residuals_and_host_arpack(ctx):
     assert rel(out["coeffs"], c_h) < TOL
     assert abs(out["Le"] - le_h) <= TOL * le_h
     assert rel(out["yfitted.std"], Kh @ c_h) < TOL
+    # ---- marginal effects and variances of ALL 20 columns from the host's K and ARPACK's pairs --------------
+    # (src/bigderiv_v3.cpp:90-106 in the oracle's O(N^2) form; V = Q diag(wv) Q', R/bigKRLS.R:299-301)
+    sigsq_h = float(np.sum((ys - Kh @ c_h) ** 2) / n)                                     # R/bigKRLS.R:294
+    assert abs(out["sigmasq"] - sigsq_h) <= TOL * sigsq_h
+    wv_h = sigsq_h * (hv[:k] + lam_h) ** -2.0
+    t0 = time.perf_counter()
+    D_h, var_h = orc.derivmat_fast(Xs, Kh, c_h, float(p), hq[:, :k], wv_h)
+    print(f"C3: host derivatives of {p} columns in {time.perf_counter() - t0:.1f} s")
+    assert out["derivatives.std"].shape == (n, p)
+    for j in range(p):
+        assert rel(out["derivatives.std"][:, j], D_h[:, j]) < TOL, j
+    assert rel(out["var.avgderivatives.std"], var_h) < TOL
+    sdy, sdx = y.std(ddof=1), X.std(0, ddof=1)
+    assert rel(out["derivatives"], D_h * sdy / sdx) < TOL                                  # R/bigKRLS.R:394-397
+    assert rel(out["avgderivatives"].ravel(), (D_h * sdy / sdx).mean(0)) < TOL             # :400
+    assert rel(out["var.avgderivatives"].ravel(), (sdy / sdx) ** 2 * var_h) < TOL          # :403-407
+    # diagonals of the variance matrices: sd(y)^2 sum_k q_ik^2 wv_k and ... d_k^2 wv_k     (:438, :445, :307)
+    q2 = hq[:, :k] ** 2
+    assert rel(out["vcov.est.c"].diag().ravel(), sdy ** 2 * (q2 @ wv_h)) < TOL
+    assert rel(out["vcov.est.fitted"].diag().ravel(), sdy ** 2 * (q2 @ (wv_h * hv[:k] ** 2))) < TOL
+    # ... and a sampled block of each against Q diag(w) Q' on the host
+    rows = np.array([0, 1, 4097, 9999, n - 1])
+    blk = sdy ** 2 * (hq[rows, :k] * wv_h) @ hq[:, :k].T
+    Vc_rows = ops.gemm(False, False, out["vcov.est.c"], ctx.from_numpy(unit_columns(n, rows))).to_numpy()   # columns = rows (symmetric)
+    assert rel(Vc_rows.T, blk) < TOL
     del Kh
 
 
@@ -228,10 +284,38 @@ def test_c4_fit_properties_and_lanczos_vs_dense(ctx, monkeypatch):
     print(f"C4: kept {k}, resid {res:.2e}, orth {orth:.2e}")
     assert res < 1e-9 and orth < 1e-11        # Lanczos stops at Ritz residuals of 1e-10 theta_1
     kept_subspace_checks(ctx, ops, out, K, eo.vectors, ys, n)
-    derivative_identities(ctx, ops, out, K, Xs, [0, 11], float(p))
-    assert np.isfinite(out["derivatives"]).all() and np.all(out["var.avgderivatives"] > 0)
+    derivative_identities(ctx, ops, out, K, Xs, range(p), float(p))
+    assert np.isfinite(out["derivatives"]).all()
     sd2 = y.std(ddof=1) ** 2
     lam = out["lambda"]
+    # var(avg derivative) of every column, standardised: 4/(sigma^2 n^2) s'Vs with s = x o K1 - K x and
+    # V = Q diag(wv) Q' (src/bigderiv_v3.cpp:105 in its O(N^2) form), from plain matvecs
+    wv = out["sigmasq"] * (d[:k] + lam) ** -2.0
+    K1 = ops.matvec(K, ctx.from_numpy(np.ones(n))).to_numpy().ravel()
+    sdx, sdy = X.std(0, ddof=1), y.std(ddof=1)
+    for j in range(p):
+        x = Xs[:, j]
+        s_j = x * K1 - ops.matvec(K, ctx.from_numpy(x)).to_numpy().ravel()
+        qs = ops.matvec(eo.vectors, ctx.from_numpy(s_j), trans=True).to_numpy().ravel()
+        want = 4.0 / (float(p) ** 2 * float(n) ** 2) * float(np.sum(wv * qs * qs))
+        assert abs(out["var.avgderivatives.std"][j] - want) <= 1e-8 * want, j
+    assert rel(out["var.avgderivatives"].ravel(), (sdy / sdx) ** 2 * out["var.avgderivatives.std"]) < 1e-13
+    assert rel(out["derivatives"], out["derivatives.std"] * sdy / sdx) < 1e-13
+    # three columns and the variance-matrix diagonals against the HOST: K rows pulled from the device, products
+    # with numpy (nothing of the library in the expected values but the kernel entries, which C3 pins to 1e-13)
+    c_fit, Kc_fit = out["coeffs"], out["yfitted.std"]
+    Qh = eo.vectors.to_numpy()
+    for j in (0, 11, 19):
+        x = Xs[:, j]
+        rows = np.array([3, 25000, n - 2])
+        Krows = ops.gemm(False, False, K, ctx.from_numpy(unit_columns(n, rows))).to_numpy().T   # 3 x n rows of K
+        assert rel(Krows[0], orc.temp_kernel_literal(Xs, Xs[rows[:1]], float(p)).ravel()) < 1e-13
+        want = (-2.0 / float(p)) * (x[rows] * (Krows @ c_fit) - Krows @ (x * c_fit))         # src/bigderiv_v3.cpp:103
+        assert rel(out["derivatives.std"][rows, j], want) < TOL, j
+    q2 = Qh[:, :k] ** 2
+    assert rel(out["vcov.est.c"].diag().ravel(), sd2 * (q2 @ wv)) < TOL
+    assert rel(out["vcov.est.fitted"].diag().ravel(), sd2 * (q2 @ (wv * d[:k] ** 2))) < TOL
+    del Qh, q2
     tv = out["vcov.est.c"].diag().sum() / sd2
     tf = out["vcov.est.fitted"].diag().sum() / sd2
     assert abs(tv - out["sigmasq"] * np.sum((d[:k] + lam) ** -2.0)) < 1e-8 * tv
