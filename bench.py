@@ -266,6 +266,8 @@ def main():
             pass
         print(json.dumps(res), flush=True)
     if world > 1 or args.force_dist:
+        from bigkrls_amd import dist as bkdist
+        bkdist.release_comms()
         dist.destroy_process_group()
 
 
@@ -282,7 +284,9 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
         from bigkrls_amd import dist as bkdist
 
         def one_fit(timings):
-            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=False, **fit_kw)
+            # the same outputs as the single-GPU fit (the variance matrices are computed only when asked for): this
+            # rank's column blocks of K, vcov.est.c, vcov.est.fitted
+            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=True, **fit_kw)
     else:
         def one_fit(timings):
             return bk.bigKRLS(y, X, ctx=ctx, timings=timings, **fit_kw)

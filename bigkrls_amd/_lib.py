@@ -125,7 +125,26 @@ SIGNATURES = {
     # level 2, whole path
     "bigkrls_fit": [vp, vp, vp, i64, i64, C.POINTER(FitOptions), C.POINTER(FitOutputs)],
     "bigkrls_predict": [vp, vp, i64, i64, vp, vp, f64, vp, i64, vp, f64, vp, vp, vp, vp],
+    # multi-GPU
+    "bigkrls_comm_unique_id": [vp],
+    "bigkrls_comm_create": [vp, i32, i32, vp, C.POINTER(vp)],
+    "bigkrls_comm_create_callbacks": [vp, i32, i32, vp, C.POINTER(vp)],
+    "bigkrls_comm_destroy": [vp],
+    "bigkrls_comm_rank": [vp, pi32, pi32],
+    "bigkrls_comm_check": [vp, vp, i64],
+    "bigkrls_fit_dist_rows": [vp, i64, C.POINTER(FitOptions), pi64, pi64],
+    "bigkrls_fit_dist": [vp, vp, vp, i64, i64, C.POINTER(FitOptions), C.POINTER(FitOutputs)],
 }
+
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, i64, i32)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, i64)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, vp, vp, i64, i32)
+
+
+class Collectives(C.Structure):
+    """bigkrls_collectives (include/bigkrls.h)."""
+    _fields_ = [("struct_bytes", i64), ("user", vp), ("all_reduce", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN),
+                ("broadcast", BROADCAST_FN)]
 _RESTYPES = {
     "bigkrls_last_error": C.c_char_p,
     "bigkrls_ctx_stream": vp,

@@ -17,6 +17,7 @@ import numpy as np
 import ctypes as C
 
 from . import _lib, ops
+from ._lib import i64
 from .device import Context, DeviceMatrix, is_device_matrix
 
 _default_ctx: Optional[Context] = None
@@ -94,7 +95,7 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
             model_subfolder_name=None, overwrite_existing=False, Ncores=None,
             acf=False, noisy=None, instructions=True, ctx: Optional[Context] = None,
             timings: Optional[Dict[str, float]] = None,
-            trace: Optional[list] = None) -> BigKRLS:
+            trace: Optional[list] = None, comm=None, keep_outputs: bool = True) -> BigKRLS:
     """Kernel-regularised least squares fit (R/bigKRLS.R:97-516).
 
     The numeric body -- validation of the data, standardisation, the five steps and the rescaling
@@ -109,8 +110,12 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     marginal effects of all columns are one pass over K on the GPU.  `timings`
     (optional dict) receives per-phase seconds measured with HIP events on the context's stream;
     `trace` (optional list) the (lambda, Le) probes of the golden-section search.
+    `comm` (a bigkrls_amd.dist.Comm): the fit runs over the ranks of that communicator -- every process calls
+    with the same y, X and arguments -- through `bigkrls_fit_dist`; the N x N outputs are then this rank's
+    column blocks `K.cols`, `vcov.est.c.cols`, `vcov.est.fitted.cols` (n x (r1 - r0), rows `w["rows"]`),
+    or not kept at all with keep_outputs=False.
     """
-    ctx = ctx or default_context()
+    ctx = (comm.ctx if comm is not None else ctx) or default_context()
     if X is None or y is None:
         raise ValueError("y and X are required")
     if model_subfolder_name is not None and not isinstance(model_subfolder_name, str):        # :112
@@ -187,15 +192,25 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
         out.derivatives, out.derivatives_std = D.ctypes.data, Dstd.ctypes.data
         out.avgderivatives, out.var_avgderivatives = avg.ctypes.data, var.ctypes.data
         out.var_avgderivatives_std = varstd.ctypes.data
-    K = ctx.empty(n, n)                                                           # :434
-    out.d_K = K.ptr
-    vcovmatc = vcovmatyhat = None
-    if vcov_est:
-        vcovmatc, vcovmatyhat = ctx.empty(n, n), ctx.empty(n, n)
-        out.d_vcov_c, out.d_vcov_fitted = vcovmatc.ptr, vcovmatyhat.ptr
+    r0, r1 = 0, n
+    if comm is not None:
+        a0, a1 = i64(0), i64(0)
+        _call_native("bigkrls_fit_dist_rows", comm.handle, n, C.byref(opt), C.byref(a0), C.byref(a1))
+        r0, r1 = int(a0.value), int(a1.value)
+    ncols = r1 - r0                                                               # columns of K this process holds
+    K = vcovmatc = vcovmatyhat = None
+    if keep_outputs or comm is None:
+        K = ctx.empty(n, max(ncols, 1))                                           # :434
+        out.d_K = K.ptr
+        if vcov_est:
+            vcovmatc, vcovmatyhat = ctx.empty(n, max(ncols, 1)), ctx.empty(n, max(ncols, 1))
+            out.d_vcov_c, out.d_vcov_fitted = vcovmatc.ptr, vcovmatyhat.ptr
 
     t_wall0 = time.perf_counter()
-    _call_native("bigkrls_fit", ctx.handle, Xh.ctypes.data, yh.ctypes.data, n, p, C.byref(opt), C.byref(out))
+    if comm is None:
+        _call_native("bigkrls_fit", ctx.handle, Xh.ctypes.data, yh.ctypes.data, n, p, C.byref(opt), C.byref(out))
+    else:
+        _call_native("bigkrls_fit_dist", comm.handle, Xh.ctypes.data, yh.ctypes.data, n, p, C.byref(opt), C.byref(out))
     t_native = time.perf_counter() - t_wall0
 
     if trace is not None:
@@ -223,13 +238,21 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     w["Looe"] = float(out.Looe)                                                   # :430
     w["Le"] = float(out.Le)
     w["sigmasq"] = float(out.sigmasq) if vcov_est else None
-    w["K"] = K if return_big_squares else K.to_numpy()                            # :434
-    if vcov_est:
-        w["vcov.est.c"] = vcovmatc if return_big_squares else vcovmatc.to_numpy()          # :438
-        w["vcov.est.fitted"] = vcovmatyhat if return_big_squares else vcovmatyhat.to_numpy()   # :445
+    if comm is not None:
+        w["rows"] = (r0, r1)
+        if keep_outputs:
+            cut = (lambda m: m if ncols > 0 else None)
+            w["K.cols"] = cut(K)
+            w["vcov.est.c.cols"] = cut(vcovmatc) if vcov_est else None
+            w["vcov.est.fitted.cols"] = cut(vcovmatyhat) if vcov_est else None
     else:
-        w["vcov.est.c"] = None
-        w["vcov.est.fitted"] = None
+        w["K"] = K if return_big_squares else K.to_numpy()                        # :434
+        if vcov_est:
+            w["vcov.est.c"] = vcovmatc if return_big_squares else vcovmatc.to_numpy()          # :438
+            w["vcov.est.fitted"] = vcovmatyhat if return_big_squares else vcovmatyhat.to_numpy()   # :445
+        else:
+            w["vcov.est.c"] = None
+            w["vcov.est.fitted"] = None
     w["derivative.call"] = derivative
     if derivative:
         w["avgderivatives"] = avg[None, :]                                        # :400

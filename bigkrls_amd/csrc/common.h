@@ -61,7 +61,7 @@ struct bigkrls_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
-  static constexpr int kSlots = 40;
+  static constexpr int kSlots = 48;
   void* ws[kSlots] = {nullptr};
   int64_t ws_bytes[kSlots] = {0};
   // pinned host scratch for small scalar read-backs
@@ -75,7 +75,38 @@ struct bigkrls_ctx {
   std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per sample costs more than the sample)
 };
 
+// One rank of a multi-GPU job (one process per GPU): the context it computes on and the collectives that connect
+// it to its peers -- RCCL (ncclCommInitRank from a caller-distributed unique id; librccl is opened at run time) or a
+// caller-supplied table of callbacks (tests: host-staged collectives that let several ranks share one GPU).
+struct bigkrls_comm {
+  bigkrls_ctx* ctx = nullptr;
+  int nranks = 1, rank = 0;
+  void* nccl = nullptr;          // ncclComm_t
+  bool use_cb = false;
+  bigkrls_collectives cb{};
+};
+
 namespace bk {
+
+enum CommOp { COMM_SUM = 0, COMM_MIN = 1 };
+// collectives on device buffers of doubles, ordered on comm->ctx->stream (in place for the reduction)
+int comm_all_reduce(bigkrls_comm* comm, double* dbuf, int64_t count, int op);
+int comm_all_gather(bigkrls_comm* comm, const double* dsend, double* drecv, int64_t count_per_rank);
+int comm_broadcast(bigkrls_comm* comm, double* dbuf, int64_t count, int root);
+// the same on a few host scalars (staged through the context's pinned buffer; synchronises the stream)
+int comm_all_reduce_host(bigkrls_comm* comm, double* h_vals, int64_t count, int op);
+// every rank returns the worst of the ranks' local status codes (one MIN all-reduce): no rank enters the next
+// collective while a peer has already failed
+int comm_agree(bigkrls_comm* comm, int local_status);
+// equal row blocks of nb = ceil(n / world) rows rounded up to a multiple of `align`; the last ranks may be short or empty
+void dist_partition(int64_t n, int world, int64_t align, int rank, int64_t* nb, int64_t* r0, int64_t* r1);
+// out (n x cols, ldo) = the row blocks `local` (nloc x cols, ldl) of all ranks stacked in rank order
+int comm_gather_rows(bigkrls_comm* comm, const double* local, int64_t nloc, int64_t ldl, int64_t cols, int64_t nb,
+                     int64_t n, double* out, int64_t ldo);
+// dense eigensolver with stage 1 partitioned by column blocks (A = K[:, c0:c1], n x ncl, ld n, overwritten);
+// vals (device, neig), Q (device, n x neig, ld n) end up replicated
+int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64_t neig, double eigtrunc,
+                     double* dvals, double* dQ, int64_t* h_lastkeeper);
 
 // workspace slot ids (each caller family uses its own so nested calls never alias)
 enum Slot {
@@ -115,6 +146,12 @@ enum Slot {
   SLOT_FIT_M = 33,         // ... Q diag(w) / K_new V
   SLOT_FIT_K = 34,         // ... the kernel when the caller does not want it back
   SLOT_EIG_AGG = 35,       // stage 1: reflector blocks of the panel groups whose trailing update is pending
+  SLOT_COMM_STAGE = 36,    // multi-GPU: send / receive staging of the row-block all-gathers
+  SLOT_COMM_SMALL = 37,    // ... status words and scalars that are all-reduced
+  SLOT_DIST_A = 38,        // ... the working copy of this rank's column block of K in the partitioned stage 1
+  SLOT_DIST_MISC = 39,     // ... panel strips and the Y = A22 V exchange buffers
+  SLOT_DIST_K = 40,        // ... this rank's column block of K when the caller does not want it back
+  SLOT_DIST_V = 41,        // ... column blocks of the variance matrices (same)
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
@@ -203,10 +240,11 @@ int qty(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq, co
 int solveforc(bigkrls_ctx* ctx, const double* Q, int64_t n_rows, int64_t k, int64_t ldq,
               const double* d, const double* a, double lambda, double* c, double* h_Le);
 int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, double* U);
-int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
+// Q: the n_rows x k row block this rank holds of the n_total x k eigenvector matrix (comm == nullptr: all of it)
+int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n_rows, int64_t k, int64_t ldq,
                   const double* d, const double* a, const double* h_vals_all, int64_t n_vals,
                   double L, double U, double tol, double* h_lambda, int64_t* h_nprobes,
-                  double* h_trace, int64_t max_trace);
+                  double* h_trace, int64_t max_trace, bigkrls_comm* comm = nullptr, int64_t n_total = 0);
 
 // ---- deriv.hip ----------------------------------------------------------------
 int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
@@ -223,6 +261,11 @@ enum EigMode { EIG_FULL = 0, EIG_SETUP_ONLY = 1, EIG_RESUME = 2 };
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
           int part_index = 0, int part_count = 1, int mode = EIG_FULL);
+// block Lanczos for the n_vals largest pairs with the products K B_j sharded over the ranks of `comm`: Kcols is this
+// rank's column block K[:, r0:r1] (n x (r1 - r0), ld n), nb the partition's block size; everything else replicated
+int eigen_krylov_dist(bigkrls_comm* comm, const double* Kcols, int64_t n, int64_t r0, int64_t r1, int64_t nb,
+                      int64_t n_vals, double* vals, int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
+                      int64_t* h_n_vecs);
 // Row-block distributed stage 1 (dense -> band), one call per panel step between the caller's
 // collectives; see include/bigkrls.h (bigkrls_dev_s1_*).
 int dist_s1_open(bigkrls_ctx* ctx, int64_t n);

@@ -1,0 +1,375 @@
+// Multi-GPU side of the library: one rank object per process (bigkrls_comm), its collectives (RCCL over xGMI, or a
+// caller-supplied callback table), the row-block gather helper and the dense eigensolver with stage 1 partitioned by
+// column blocks over the ranks. The reference's parallel path is PSOCK workers over one mmap'd K, one derivative
+// column each (R/bigKRLS.R:337-363); here K itself is partitioned by row block and never
+// gathered. bigkrls_fit_dist (csrc/fit.hip) is the whole fit over these pieces.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+namespace bk {
+namespace {
+
+// librccl is opened at run time: a single-GPU user needs no RCCL, and a process that already holds one (PyTorch
+// bundles its own) keeps using exactly that one.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {               // one that is already mapped first
+      h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+      if (h) break;
+    }
+    if (!h)
+      for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+      }
+    if (!h) {
+      api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      return;
+    }
+    auto sym = [&](const char* nm) { return dlsym(h, nm); };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather &&
+             api.Broadcast && api.GetErrorString;
+    if (!api.ok) api.why = "librccl lacks a required symbol";
+  });
+  return api;
+}
+
+int nccl_fail(const char* what, ncclResult_t r) {
+  set_error(std::string(what) + " failed: " + rccl().GetErrorString(r));
+  return BIGKRLS_EHIP;
+}
+
+#define BK_NCCL(expr)                                  \
+  do {                                                 \
+    ncclResult_t _r = (expr);                          \
+    if (_r != ncclSuccess) return nccl_fail(#expr, _r); \
+  } while (0)
+
+int cb_fail(const char* what, int rc) {
+  set_error(std::string("collective callback ") + what + " returned " + std::to_string(rc));
+  return BIGKRLS_EHIP;
+}
+
+}  // namespace
+
+int comm_all_reduce(bigkrls_comm* comm, double* dbuf, int64_t count, int op) {
+  if (!comm || count <= 0) return BIGKRLS_OK;
+  if (comm->use_cb) {
+    if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
+    const int rc = comm->cb.all_reduce(comm->cb.user, dbuf, count, op);
+    return rc ? cb_fail("all_reduce", rc) : BIGKRLS_OK;
+  }
+  BK_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclFloat64, op == COMM_MIN ? ncclMin : ncclSum,
+                           (ncclComm_t)comm->nccl, comm->ctx->stream));
+  return BIGKRLS_OK;
+}
+
+int comm_all_gather(bigkrls_comm* comm, const double* dsend, double* drecv, int64_t count) {
+  if (!comm || count <= 0) return BIGKRLS_OK;
+  if (comm->use_cb) {
+    if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
+    const int rc = comm->cb.all_gather(comm->cb.user, dsend, drecv, count);
+    return rc ? cb_fail("all_gather", rc) : BIGKRLS_OK;
+  }
+  BK_NCCL(rccl().AllGather(dsend, drecv, (size_t)count, ncclFloat64, (ncclComm_t)comm->nccl, comm->ctx->stream));
+  return BIGKRLS_OK;
+}
+
+int comm_broadcast(bigkrls_comm* comm, double* dbuf, int64_t count, int root) {
+  if (!comm || count <= 0) return BIGKRLS_OK;
+  if (comm->use_cb) {
+    if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
+    const int rc = comm->cb.broadcast(comm->cb.user, dbuf, count, root);
+    return rc ? cb_fail("broadcast", rc) : BIGKRLS_OK;
+  }
+  BK_NCCL(rccl().Broadcast(dbuf, dbuf, (size_t)count, ncclFloat64, root, (ncclComm_t)comm->nccl, comm->ctx->stream));
+  return BIGKRLS_OK;
+}
+
+int comm_all_reduce_host(bigkrls_comm* comm, double* h_vals, int64_t count, int op) {
+  if (!comm || count <= 0) return BIGKRLS_OK;
+  bigkrls_ctx* ctx = comm->ctx;
+  void* p = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_COMM_SMALL, std::max<int64_t>(count, 64) * sizeof(double), &p));
+  double* hp = nullptr;
+  BK_TRY(pinned_get(ctx, count, &hp));
+  std::memcpy(hp, h_vals, (size_t)count * sizeof(double));
+  BK_HIP(hipMemcpyAsync(p, hp, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  BK_TRY(comm_all_reduce(comm, (double*)p, count, op));
+  BK_HIP(hipMemcpyAsync(hp, p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  std::memcpy(h_vals, hp, (size_t)count * sizeof(double));
+  return BIGKRLS_OK;
+}
+
+int comm_agree(bigkrls_comm* comm, int local_status) {
+  if (!comm) return local_status;
+  // the all-reduce itself must not be skipped by a failed rank: its peers are waiting in it
+  std::string local_msg = local_status != BIGKRLS_OK ? std::string(bigkrls_last_error()) : std::string();
+  double v = -(double)local_status;      // MIN of the negated codes = the largest code
+  const int rc = comm_all_reduce_host(comm, &v, 1, COMM_MIN);
+  if (local_status != BIGKRLS_OK) {
+    set_error(local_msg);
+    return local_status;
+  }
+  if (rc != BIGKRLS_OK) return rc;
+  const int worst = (int)(-v + 0.5);
+  if (worst != BIGKRLS_OK) {
+    set_error("another rank of the multi-GPU fit failed with status " + std::to_string(worst));
+    return worst;
+  }
+  return BIGKRLS_OK;
+}
+
+void dist_partition(int64_t n, int world, int64_t align, int rank, int64_t* nb, int64_t* r0, int64_t* r1) {
+  int64_t b = (n + world - 1) / world;
+  b = (b + align - 1) / align * align;
+  if (nb) *nb = b;
+  if (r0) *r0 = std::min<int64_t>((int64_t)rank * b, n);
+  if (r1) *r1 = std::min<int64_t>((int64_t)(rank + 1) * b, n);
+}
+
+int comm_gather_rows(bigkrls_comm* comm, const double* local, int64_t nloc, int64_t ldl, int64_t cols, int64_t nb,
+                     int64_t n, double* out, int64_t ldo) {
+  bigkrls_ctx* ctx = comm->ctx;
+  const int world = comm->nranks;
+  void* p = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(world + 1) * nb * cols * sizeof(double), &p));
+  double* send = (double*)p;
+  double* recv = send + nb * cols;
+  if (nloc < nb) BK_HIP(hipMemsetAsync(send, 0, (size_t)(nb * cols) * sizeof(double), ctx->stream));
+  if (nloc > 0) BK_TRY(copy_matrix(ctx, local, nloc, cols, ldl, send, nb));
+  BK_TRY(comm_all_gather(comm, send, recv, nb * cols));
+  for (int r = 0; r < world; ++r) {
+    const int64_t lo = (int64_t)r * nb, rows = std::min<int64_t>(nb, n - lo);
+    if (rows <= 0) break;
+    BK_TRY(copy_matrix(ctx, recv + (int64_t)r * nb * cols, rows, cols, nb, out + lo, ldo));
+  }
+  return BIGKRLS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dense symmetric eigendecomposition with stage 1 (dense -> band, 4/3 N^3 flops) partitioned by column blocks
+// ("Eigen, dense tridiagonalisation"). Per 64-column panel: one broadcast of the panel
+// strip from its owner, the replicated panel QR, this rank's rows of Y = A22 V (A22 symmetric: its own columns,
+// transposed), one all-gather of Y (N x 64), the replicated thin products, and the update of the own columns --
+// with look-ahead: the columns of the NEXT panel are updated first by their owner, its strip is broadcast and its
+// factorisation started on the look-ahead stream beside the update of the remaining columns. The reduced matrix
+// ends up replicated; stage 2 and the divide & conquer are replicated (latency-bound, no flops to share), the
+// back-transform is split by eigenvector column and assembled with an all-gather of the column blocks -- the RCCL
+// exchange north_star names. A rank that fails locally keeps taking part in the collectives of the loop (its peers
+// are inside them) and the failure is agreed on before the next phase.
+// ---------------------------------------------------------------------------------------------------------------
+int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64_t neig, double eigtrunc,
+                     double* dvals, double* dQ, int64_t* h_lastkeeper) {
+  bigkrls_ctx* ctx = comm->ctx;
+  hipStream_t st = ctx->stream;
+  const int world = comm->nranks, rank = comm->rank;
+  constexpr int64_t b = 64;
+  BK_REQUIRE(nb % b == 0 && n > 4 * b, "eigen_dense_dist: the column blocks must be multiples of 64 and n > 256");
+  const int64_t c0 = std::min<int64_t>((int64_t)rank * nb, n), c1 = std::min<int64_t>((int64_t)(rank + 1) * nb, n);
+  const int64_t ncl = c1 - c0;
+  int live = comm_agree(comm, dist_s1_open(ctx, n));
+  BK_TRY(live);
+  void* pm = nullptr;
+  // strip (n x 64), Ysend (nb x 64), Yrecv (world x nb x 64), Y (n x 64)
+  BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_MISC, (2 * n * b + (int64_t)(world + 1) * nb * b) * sizeof(double), &pm)));
+  double* sbuf = (double*)pm;
+  double* Ysend = sbuf + n * b;
+  double* Yrecv = Ysend + nb * b;
+  double* Y = Yrecv + (int64_t)world * nb * b;
+  BK_HIP(hipMemsetAsync(Ysend, 0, (size_t)(nb * b) * sizeof(double), st));
+  auto has_panel = [&](int64_t k) { return k + b < n && n - k - b > 1; };
+  int status = BIGKRLS_OK;       // first local failure; collectives keep running
+  auto local = [&](int rc) {
+    if (rc != BIGKRLS_OK && status == BIGKRLS_OK) status = rc;
+  };
+  // rows k..n of the global columns k..k+w (inside one owner's block) on every rank, as an (n - k) x w matrix
+  auto bcast_strip = [&](int64_t k, int64_t w) -> int {
+    const int owner = (int)(k / nb);
+    if (owner == rank && status == BIGKRLS_OK) local(copy_matrix(ctx, A + (k - c0) * n + k, n - k, w, n, sbuf, n - k));
+    return comm_broadcast(comm, sbuf, w * (n - k), owner);
+  };
+  int64_t k = 0;
+  if (has_panel(0)) {
+    BK_TRY(bcast_strip(0, b));
+    if (status == BIGKRLS_OK) local(dist_s1_panel(ctx, n, 0, sbuf));
+  }
+  while (has_panel(k)) {
+    const int64_t m = n - k - b;
+    const int64_t la0 = std::min<int64_t>(std::max<int64_t>(k + b - c0, 0), ncl);   // first own column inside the trailing matrix
+    const int64_t nact = ncl - la0;
+    double* Aact = A + la0 * n + (k + b);
+    if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, Ysend + la0, nb));   // (waits for panel k's factorisation)
+    BK_TRY(comm_all_gather(comm, Ysend, Yrecv, nb * b));
+    if (status == BIGKRLS_OK) {
+      // rows k+b .. n of Y = A22 V from the ranks' blocks
+      for (int r = 0; r < world; ++r) {
+        const int64_t lo = std::max<int64_t>((int64_t)r * nb, k + b), hi = std::min<int64_t>((int64_t)(r + 1) * nb, n);
+        if (hi <= lo) continue;
+        local(copy_matrix(ctx, Yrecv + (int64_t)r * nb * b + (lo - (int64_t)r * nb), hi - lo, b, nb, Y + (lo - (k + b)), m));
+      }
+      local(dist_s1_thin(ctx, n, k, Y));
+    }
+    const int64_t row0 = nact > 0 ? (c0 + la0) - (k + b) : 0;
+    const int64_t nxt = k + b;
+    int64_t first = 0;                                   // own columns already updated before the look-ahead
+    if (has_panel(nxt)) {
+      if (nxt / nb == rank) {                            // the next panel's columns are the first active ones of their owner
+        first = std::min<int64_t>(b, nact);
+        if (status == BIGKRLS_OK) local(dist_s1_update_cols(ctx, n, k, Aact, n, first, row0));
+      }
+      BK_TRY(bcast_strip(nxt, b));
+      if (status == BIGKRLS_OK) local(dist_s1_panel_begin(ctx, n, nxt, sbuf));
+    }
+    if (status == BIGKRLS_OK) local(dist_s1_update_cols(ctx, n, k, Aact + first * n, n, nact - first, row0 + first));
+    k += b;
+  }
+  while (k < n) {                                        // what is left of the trailing matrix: not panels
+    const int64_t owner_end = std::min<int64_t>((k / nb + 1) * nb, n);
+    const int64_t w = std::min<int64_t>(b, owner_end - k);
+    BK_TRY(bcast_strip(k, w));
+    if (status == BIGKRLS_OK) local(dist_s1_put(ctx, n, k, sbuf, w));
+    k += w;
+  }
+  BK_TRY(comm_agree(comm, status));
+  // stage 2, divide & conquer and this rank's slice of the back-transform; a fired watchdog of the distributed
+  // stage 1 cannot be replayed and comes back as an error -- on every rank
+  int64_t nv = 0;
+  void* pq = nullptr;
+  status = eigen(ctx, nullptr, n, n, neig, dvals, neig, eigtrunc, dQ, n, &nv, rank, world, EIG_RESUME);
+  BK_TRY(comm_agree(comm, status));
+  if (h_lastkeeper) *h_lastkeeper = nv;
+  if (world == 1 || nv == 0) return BIGKRLS_OK;
+  // all-gather of the back-transformed column blocks (rank r holds columns nv r / world .. nv (r + 1) / world)
+  int64_t pmax = 0;
+  for (int r = 0; r < world; ++r) pmax = std::max<int64_t>(pmax, nv * (r + 1) / world - nv * r / world);
+  BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(world + 1) * pmax * n * sizeof(double), &pq)));
+  double* send = (double*)pq;
+  double* recv = send + pmax * n;
+  const int64_t my0 = nv * rank / world, mine = nv * (rank + 1) / world - my0;
+  BK_HIP(hipMemsetAsync(send, 0, (size_t)(pmax * n) * sizeof(double), st));
+  if (mine > 0) BK_HIP(hipMemcpyAsync(send, dQ + my0 * n, (size_t)(mine * n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BK_TRY(comm_all_gather(comm, send, recv, pmax * n));
+  for (int r = 0; r < world; ++r) {
+    const int64_t q0 = nv * r / world, cnt = nv * (r + 1) / world - q0;
+    if (cnt > 0)
+      BK_HIP(hipMemcpyAsync(dQ + q0 * n, recv + (int64_t)r * pmax * n, (size_t)(cnt * n) * sizeof(double),
+                            hipMemcpyDeviceToDevice, st));
+  }
+  return BIGKRLS_OK;
+}
+
+}  // namespace bk
+
+using namespace bk;
+
+extern "C" {
+
+int bigkrls_comm_unique_id(void* id_out) {
+  BK_REQUIRE(id_out, "comm_unique_id: null output");
+  static_assert(sizeof(ncclUniqueId) == BIGKRLS_UNIQUE_ID_BYTES, "unique id size");
+  if (!rccl().ok) {
+    set_error("RCCL is not available: " + rccl().why);
+    return BIGKRLS_ENODEVICE;
+  }
+  ncclUniqueId id;
+  BK_NCCL(rccl().GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof id);
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_create(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const void* unique_id, bigkrls_comm** out) {
+  BK_REQUIRE(ctx && unique_id && out, "comm_create: null argument");
+  BK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_create: bad rank / nranks");
+  if (!rccl().ok) {
+    set_error("RCCL is not available: " + rccl().why);
+    return BIGKRLS_ENODEVICE;
+  }
+  BK_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  ncclComm_t c = nullptr;
+  BK_NCCL(rccl().CommInitRank(&c, nranks, id, rank));
+  bigkrls_comm* comm = new bigkrls_comm();
+  comm->ctx = ctx;
+  comm->nranks = nranks;
+  comm->rank = rank;
+  comm->nccl = (void*)c;
+  *out = comm;
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_create_callbacks(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const bigkrls_collectives* table,
+                                  bigkrls_comm** out) {
+  BK_REQUIRE(table && out, "comm_create_callbacks: null argument");
+  BK_REQUIRE(table->struct_bytes == (int64_t)sizeof(bigkrls_collectives), "comm_create_callbacks: table struct size mismatch");
+  BK_REQUIRE(table->all_reduce && table->all_gather && table->broadcast, "comm_create_callbacks: a callback is missing");
+  BK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_create_callbacks: bad rank / nranks");
+  bigkrls_comm* comm = new bigkrls_comm();
+  comm->ctx = ctx;
+  comm->nranks = nranks;
+  comm->rank = rank;
+  comm->use_cb = true;
+  comm->cb = *table;
+  *out = comm;
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_destroy(bigkrls_comm* comm) {
+  if (!comm) return BIGKRLS_OK;
+  if (comm->nccl) {
+    if (comm->ctx) (void)hipStreamSynchronize(comm->ctx->stream);
+    (void)rccl().CommDestroy((ncclComm_t)comm->nccl);
+  }
+  delete comm;
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_rank(bigkrls_comm* comm, int32_t* rank, int32_t* nranks) {
+  BK_REQUIRE(comm, "comm_rank: null communicator");
+  if (rank) *rank = comm->rank;
+  if (nranks) *nranks = comm->nranks;
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_check(bigkrls_comm* comm, double* buf, int64_t count) {
+  BK_REQUIRE(comm && buf && count > 0, "comm_check: bad arguments");
+  BK_TRY(comm_all_reduce(comm, buf, count, COMM_SUM));
+  BK_TRY(comm_all_reduce(comm, buf + count, count, COMM_MIN));
+  BK_TRY(comm_all_gather(comm, buf + 2 * count, buf + 4 * count, count));
+  BK_TRY(comm_broadcast(comm, buf + 3 * count, count, comm->nranks - 1));
+  if (comm->ctx && !comm->use_cb) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
+  return BIGKRLS_OK;
+}
+
+}  // extern "C"

@@ -1870,7 +1870,34 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
 
 static thread_local std::string kry_diag;   // what the last block Lanczos did at its convergence checks (for the error text)
 
-static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t k, double* vals,
+// W (n x cols, ld n) = K B (n x cols, ld n): the only way the block Lanczos touches K. Single GPU: the whole matrix
+// A. Multi-GPU: this rank's column block Kcols = K[:, r0:r1] gives the rows r0:r1 of K B (K symmetric: Kcols' B),
+// one all-gather of the row blocks assembles the product on every rank ("Eigen, partial").
+struct KTimes {
+  const double* A = nullptr;
+  int64_t lda = 0;
+  bigkrls_comm* comm = nullptr;
+  const double* Kcols = nullptr;
+  int64_t r0 = 0, r1 = 0, nb = 0;
+};
+
+static int k_times(bigkrls_ctx* ctx, const KTimes& op, int64_t n, const double* B, int64_t cols, double* W) {
+  if (!op.comm) return gemm(ctx, 0, 0, n, cols, n, 1.0, op.A, op.lda, B, n, 0.0, W, n);
+  const int64_t nloc = op.r1 - op.r0;
+  // the local rows go straight into their place in W; the gather then overwrites all of W (own rows unchanged)
+  if (nloc > 0) BK_TRY(gemm(ctx, 1, 0, nloc, cols, n, 1.0, op.Kcols, n, B, n, 0.0, W + op.r0, n));
+  return comm_gather_rows(op.comm, W + op.r0, nloc, n, cols, op.nb, n, W, n);
+}
+
+// control decisions of the iteration (breakdown, convergence, verification) on values agreed by all ranks: a
+// last-bit difference between replicas must never let one rank leave the loop while the others enter the next
+// all-gather. Element-wise minimum over the ranks.
+static int kry_agree_min(const KTimes& op, double* vals, int count) {
+  if (!op.comm) return BIGKRLS_OK;
+  return comm_all_reduce_host(op.comm, vals, count, COMM_MIN);
+}
+
+static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t k, double* vals,
                         int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
                         int64_t* h_n_vecs, int part_index, int part_count) {
   hipStream_t st = ctx->stream;
@@ -1898,6 +1925,11 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
   // ---- B_0 ----------------------------------------------------------------------------------
   BK_TRY(fill_random(ctx, W, n * b, 20240229u));
   BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown));
+  {
+    double okv = breakdown ? 0.0 : 1.0;
+    BK_TRY(kry_agree_min(kop, &okv, 1));
+    breakdown = !(okv > 0.5);
+  }
   BK_REQUIRE(!breakdown, "eigen (Krylov): start block is rank deficient");
   BK_HIP(hipMemcpyAsync(B, W, n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
   int steps = 0;
@@ -1917,7 +1949,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     const double* Bj = B + (int64_t)steps * b * n;
     // (bench.py: HIP-event sampling of the step's dominant product, 2 n^2 b flops, every launch)
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_kb", 2.0 * (double)n * (double)n * b));
-    BK_TRY(gemm(ctx, 0, 0, n, b, n, 1.0, A, lda, Bj, n, 0.0, W, n));
+    BK_TRY(k_times(ctx, kop, n, Bj, b, W));
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_kb"));
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_cgs2", 8.0 * (double)n * (double)dim * b));
     for (int pass = 0; pass < 2; ++pass) {
@@ -1929,6 +1961,11 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_cgs2"));
     BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b));   // synchronises the stream
     ++steps;
+    {
+      double okv = breakdown ? 0.0 : 1.0;
+      BK_TRY(kry_agree_min(kop, &okv, 1));
+      breakdown = !(okv > 0.5);
+    }
     const bool last = breakdown || steps >= maxsteps;
     // ---- convergence check on the projected problem ---------------------------------------------
     if (last || steps >= next_check) {
@@ -1973,6 +2010,13 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
           if (keep_thresh >= 0.0 && theta[i] >= keep_thresh * theta[0]) worst_kept = std::max(worst_kept, std::sqrt(r2));
         }
       }
+      double theta1 = std::fabs(theta[0]);
+      {
+        double ag[2] = {-worst, theta1};     // the largest residual and the smallest theta_1 over the ranks
+        BK_TRY(kry_agree_min(kop, ag, 2));
+        worst = -ag[0];
+        theta1 = ag[1];
+      }
       if (getenv("BIGKRLS_VERBOSE"))
         fprintf(stderr, "[bigkrls] block Lanczos check: steps=%d worst=%.3e worst(kept)=%.3e converged=%lld of %lld theta0=%.4e\n",
                 steps, worst, worst_kept, (long long)n_conv, (long long)k, theta[0]);
@@ -1981,8 +2025,8 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
         snprintf(buf, sizeof buf, " [check steps=%d worst=%.3e theta0=%.6e breakdown=%d]", steps, worst, theta[0], (int)breakdown);
         kry_diag += buf;
       }
-      if (worst <= tol * std::fabs(theta[0]) || last) {
-        converged = worst <= tol * std::fabs(theta[0]);
+      if (worst <= tol * theta1 || last) {
+        converged = worst <= tol * theta1;
         dim = m;
         break;
       }
@@ -1993,7 +2037,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
       // collapse rate is used instead: an optimistic rate where a check (a dense eigensolve of T, ~12 us per
       // row) is cheaper than a step (2 n^2 b flops), so undershooting costs little, a cautious one otherwise.
       const double gain = check_is_cheap ? 40.0 : 15.0;
-      int inc = (worst > 0.0) ? (int)std::ceil(std::log(worst / (tol * std::fabs(theta[0]))) / std::log(gain)) : 1;
+      int inc = (worst > 0.0) ? (int)std::ceil(std::log(worst / (tol * theta1)) / std::log(gain)) : 1;
       inc = std::max(1, std::min(inc, std::max(2, steps / 2)));
       next_check = steps + inc;
       if (getenv("BIGKRLS_KRY_CHECK_EVERY")) next_check = steps + 1;   // (development: the convergence history)
@@ -2040,7 +2084,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     void* pT = nullptr;
     BK_TRY(ws_get(ctx, SLOT_KRY_T, (dim * dim + dim) * sizeof(double), &pT));
     const double* dtheta = (const double*)pT + dim * dim;
-    BK_TRY(gemm(ctx, 0, 0, n, bs, n, 1.0, A, lda, Q + c0 * n, n, 0.0, KQ, n));
+    BK_TRY(k_times(ctx, kop, n, Q + c0 * n, bs, KQ));
     hipLaunchKernelGGL(kry_resid_sq_kernel, dim3((unsigned)bs), dim3(256), 0, st, (const double*)KQ,
                        (const double*)(Q + c0 * n), dtheta + c0, n, dvalsH);
     BK_CHECK_LAUNCH();
@@ -2053,12 +2097,16 @@ static int eigen_krylov(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t ld
     if (getenv("BIGKRLS_VERBOSE"))
       fprintf(stderr, "[bigkrls] block Lanczos: true residual of the last %lld pairs %.3e (tolerance %.3e)\n", (long long)bs,
               rmax, tol * std::fabs(theta[0]));
-    if (!(rmax <= 10.0 * tol * std::fabs(theta[0]))) refine = true;    // also NaN
+    {
+      double ag[2] = {-rmax, std::fabs(theta[0])};
+      BK_TRY(kry_agree_min(kop, ag, 2));
+      if (!(-ag[0] <= 10.0 * tol * ag[1])) refine = true;    // also NaN
+    }
     dvals_final = dtheta;
   }
   void* pZ = nullptr;
   if (refine) {
-    BK_TRY(gemm(ctx, 0, 0, n, k, n, 1.0, A, lda, Q, n, 0.0, KQ, n));
+    BK_TRY(k_times(ctx, kop, n, Q, k, KQ));
     BK_TRY(gemm(ctx, 1, 0, k, k, n, 1.0, Q, n, KQ, n, 0.0, dH, k));
     BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
     int64_t nvZ = 0;
@@ -2113,6 +2161,20 @@ static int eigen_retry_without_resident(bigkrls_ctx* ctx, const double* A, int64
   return rc;
 }
 
+int eigen_krylov_dist(bigkrls_comm* comm, const double* Kcols, int64_t n, int64_t r0, int64_t r1, int64_t nb,
+                      int64_t n_vals, double* vals, int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
+                      int64_t* h_n_vecs) {
+  BK_REQUIRE(comm && comm->ctx && (Kcols || r1 <= r0) && vals && n_vals > 0 && n_vals <= n, "eigen_krylov_dist: bad arguments");
+  KTimes op;
+  op.comm = comm;
+  op.Kcols = Kcols;
+  op.r0 = r0;
+  op.r1 = r1;
+  op.nb = nb;
+  // every rank keeps all the kept eigenvector columns (part 0 of 1): the later passes work on row blocks of Q
+  return eigen_krylov(comm->ctx, op, n, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, 0, 1);
+}
+
 // Stage-1 state of a row-block distributed reduction, kept in the context between
 // bigkrls_dev_s1_open and bigkrls_dev_eigen_resume.
 struct DistS1 {
@@ -2141,7 +2203,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     // (measured: N = 12 000, Neig = 512 dense 0.33 s vs 0.47 s; N = 50 000, Neig = 512 dense 6.9 s vs 0.88 s)
     const bool small_k = n_vals * 8 <= n64 && n64 >= 16384;
     if (mode != "dense" && n_vals < n64 && (small_k || (mode == "krylov" && n_vals * 4 <= n64 && n64 >= 1024))) {
-      const int rc = eigen_krylov(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs,
+      KTimes whole;
+      whole.A = A;
+      whole.lda = lda;
+      const int rc = eigen_krylov(ctx, whole, n64, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs,
                                   part_index, part_count);
       // A spectrum the iteration does not resolve within its subspace limit (or a breakdown) is
       // handed to the dense path in the same call -- A is untouched. Only an explicit
@@ -2538,7 +2603,20 @@ int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, i
   BK_REQUIRE(m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m, "s1_update_cols: bad arguments");
   if (ncols == 0) return BIGKRLS_OK;
   BK_REQUIRE(Acols && lda >= m, "s1_update_cols: bad column block");
-  return gemm(ctx, 0, 1, m, ncols, 2 * S2_B, -1.0, ds->ops.ws.PZ1, m, ds->ops.ws.PZ2 + row0, m, 1.0, Acols, lda);
+  const double *PZ1 = ds->ops.ws.PZ1, *PZ2 = ds->ops.ws.PZ2;
+  // The own columns' diagonal block (rows row0 .. row0 + ncols of the trailing matrix) is symmetric: lower tiles
+  // computed and mirrored (half the MFMA work of the plain product; with one rank that is the whole update);
+  // the rows above and below it are plain products.
+  if (ncols >= 128) {
+    if (row0 > 0) BK_TRY(gemm(ctx, 0, 1, row0, ncols, 2 * S2_B, -1.0, PZ1, m, PZ2 + row0, m, 1.0, Acols, lda));
+    BK_TRY(syrk_mirror(ctx, ncols, 2 * S2_B, -1.0, PZ1 + row0, m, PZ2 + row0, m, Acols + row0, lda, 0, -1, true));
+    const int64_t below = m - row0 - ncols;
+    if (below > 0)
+      BK_TRY(gemm(ctx, 0, 1, below, ncols, 2 * S2_B, -1.0, PZ1 + row0 + ncols, m, PZ2 + row0, m, 1.0,
+                  Acols + row0 + ncols, lda));
+    return BIGKRLS_OK;
+  }
+  return gemm(ctx, 0, 1, m, ncols, 2 * S2_B, -1.0, PZ1, m, PZ2 + row0, m, 1.0, Acols, lda);
 }
 
 int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,

@@ -117,8 +117,27 @@ using namespace bk;
 
 extern "C" {
 
-int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t n, int64_t p,
-                const bigkrls_fit_options* opt, bigkrls_fit_outputs* out) {
+// The rows a rank owns and the eigensolver a multi-GPU fit uses: block Lanczos with sharded
+// K B_j products when Neig << N (like the single-GPU library), otherwise the dense path with stage 1 partitioned by
+// column blocks (64-column panels must not straddle two ranks), tiny problems replicated.
+enum DistEigen { DE_KRYLOV = 0, DE_DENSE = 1, DE_REPLICATED = 2 };
+static int dist_plan(bigkrls_comm* comm, int64_t n, const bigkrls_fit_options* opt, int* mode, int64_t* nb,
+                     int64_t* r0, int64_t* r1) {
+  const int64_t neig = (opt->neig > 0) ? std::min<int64_t>(n, opt->neig) : n;
+  int m = (neig * 8 <= n && n >= 16384) ? DE_KRYLOV : (n > 256 ? DE_DENSE : DE_REPLICATED);
+  if (const char* e = getenv("BIGKRLS_DIST_EIGEN")) {
+    const std::string v = e;
+    if (v == "krylov" && neig < n && neig * 4 <= n) m = DE_KRYLOV;
+    else if (v == "dense" && n > 256) m = DE_DENSE;
+    else if (v == "replicated") m = DE_REPLICATED;
+  }
+  *mode = m;
+  dist_partition(n, comm->nranks, m == DE_DENSE ? 64 : 1, comm->rank, nb, r0, r1);
+  return BIGKRLS_OK;
+}
+
+static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                    const bigkrls_fit_options* opt, bigkrls_fit_outputs* out) {
   BK_TRY(fit_check_ctx(ctx));
   BK_REQUIRE(h_X && h_y && opt && out, "fit: null argument");
   BK_REQUIRE(opt->struct_bytes == (int64_t)sizeof(bigkrls_fit_options), "fit: options struct size mismatch");
@@ -186,8 +205,14 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
     }
   }
 
+  // ---- the rows this rank owns (comm == nullptr: all of them) -----------------------------------------
+  int dist_mode = DE_REPLICATED;
+  int64_t nb = n, r0 = 0, r1 = n;
+  if (comm) BK_TRY(dist_plan(comm, n, opt, &dist_mode, &nb, &r0, &r1));
+  const int64_t nloc = r1 - r0;
+
   // ---- workspace ---------------------------------------------------------------------------------
-  const int64_t small_doubles = n * p + n * (3 + 3 * std::max<int64_t>(pd, 1)) + 3 * neig + 64;
+  const int64_t small_doubles = n * p + n * (3 + 5 * std::max<int64_t>(pd, 1)) + 3 * neig + 64;
   void *psmall = nullptr, *pq = nullptr;
   BK_TRY(ws_get(ctx, SLOT_FIT_SMALL, small_doubles * (int64_t)sizeof(double), &psmall));
   BK_TRY(ws_get(ctx, SLOT_FIT_Q, n * neig * (int64_t)sizeof(double), &pq));
@@ -199,14 +224,17 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   double* dXe = q; q += n * std::max<int64_t>(pd, 1);
   double* dD = q; q += n * std::max<int64_t>(pd, 1);
   double* dS = q; q += n * std::max<int64_t>(pd, 1);
+  double* dDloc = q; q += n * std::max<int64_t>(pd, 1);    // row-block results before their all-gather
+  double* dSloc = q; q += n * std::max<int64_t>(pd, 1);
   double* dvals = q; q += neig;
   double* da = q; q += neig;
   double* dw = q; q += neig;
   double* dQ = (double*)pq;
+  // K: the whole matrix, or this rank's column block K[:, r0:r1) (n x nloc, ld n)
   double* dK = out->d_K;
   if (!dK) {
     void* pk = nullptr;
-    BK_TRY(ws_get(ctx, SLOT_FIT_K, n * n * (int64_t)sizeof(double), &pk));
+    BK_TRY(ws_get(ctx, comm ? SLOT_DIST_K : SLOT_FIT_K, n * std::max<int64_t>(nloc, 1) * (int64_t)sizeof(double), &pk));
     dK = (double*)pk;
   }
   double* pin = nullptr;
@@ -230,12 +258,43 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   timer.mark();                                                           // h2d
 
   // ---- step 1: kernel (:262) ----------------------------------------------------------------------
-  BK_TRY(kernel_block(ctx, dX, n, n, dX, n, n, p, sigma, dK, n, 0));
+  if (!comm) BK_TRY(kernel_block(ctx, dX, n, n, dX, n, n, p, sigma, dK, n, 0));
+  else if (nloc > 0) BK_TRY(kernel_block(ctx, dX, n, n, dX + r0, nloc, n, p, sigma, dK, n, r0));   // K[:, r0:r1): no exchange
   timer.mark();                                                           // kernel
 
   // ---- step 2: eigen (:266-269; bEigen's lastkeeper rule on the device side) ------------------------
   int64_t lastkeeper = 0;
-  BK_TRY(eigen(ctx, dK, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper));
+  if (!comm) {
+    BK_TRY(eigen(ctx, dK, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper));
+  } else if (dist_mode == DE_KRYLOV) {
+    BK_TRY(eigen_krylov_dist(comm, dK, n, r0, r1, nb, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper));
+  } else if (dist_mode == DE_DENSE) {
+    // the reduction overwrites its operand: it works on a copy of the column block
+    void* pa = nullptr;
+    BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_A, n * std::max<int64_t>(nloc, 1) * (int64_t)sizeof(double), &pa)));
+    if (nloc > 0) BK_HIP(hipMemcpyAsync(pa, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    BK_TRY(eigen_dense_dist(comm, (double*)pa, n, nb, neig, eigtrunc, dvals, dQ, &lastkeeper));
+  } else {
+    // tiny problems: K gathered (its column blocks are row blocks of K' = K), the decomposition replicated with the
+    // back-transform split by eigenvector column, Q assembled by an all-reduce (sum)
+    void* pa = nullptr;
+    BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_A, n * n * (int64_t)sizeof(double), &pa)));
+    double* Kfull = (double*)pa;
+    // K[:, r0:r1) as the rows r0:r1 of K' (nloc x n, ld nloc would need a transpose): gather the columns instead,
+    // as blocks of nb columns = contiguous slabs of n nb doubles
+    {
+      void* pst = nullptr;
+      BK_TRY(ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(comm->nranks + 1) * nb * n * (int64_t)sizeof(double), &pst));
+      double* send = (double*)pst;
+      double* recv = send + nb * n;
+      BK_HIP(hipMemsetAsync(send, 0, (size_t)(nb * n) * sizeof(double), st));
+      if (nloc > 0) BK_HIP(hipMemcpyAsync(send, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      BK_TRY(comm_all_gather(comm, send, recv, nb * n));
+      BK_HIP(hipMemcpyAsync(Kfull, recv, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    BK_TRY(comm_agree(comm, eigen(ctx, Kfull, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper, comm->rank, comm->nranks)));
+    if (lastkeeper > 0) BK_TRY(comm_all_reduce(comm, dQ, n * lastkeeper, COMM_SUM));
+  }
   BK_TRY(pinned_get(ctx, pin_doubles, &pin));   // (the eigensolver may have grown -- and so moved -- the pinned buffer)
   std::vector<double> vals(neig);
   BK_TRY(download(ctx, vals.data(), dvals, neig, pin));
@@ -248,13 +307,20 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   timer.mark();                                                           // eigen
 
   // ---- step 3: lambda (:271-278; `tol` is never forwarded by the reference: 1e-3 n) -----------------
-  BK_TRY(qty(ctx, dQ, n, k, n, dy, da));
+  if (!comm) {
+    BK_TRY(qty(ctx, dQ, n, k, n, dy, da));
+  } else {
+    // a = Q'y from the row blocks: one all-reduce of K doubles
+    if (nloc > 0) BK_TRY(qty(ctx, dQ + r0, nloc, k, n, dy + r0, da));
+    else BK_HIP(hipMemsetAsync(da, 0, (size_t)k * sizeof(double), st));
+    BK_TRY(comm_all_reduce(comm, da, k, COMM_SUM));
+  }
   double lambda = opt->lambda;
   int64_t nprobes = 0;
   if (!(lambda > 0.0)) {
     if (opt->U >= 0.0 && !(opt->U > 0.0)) return fail("U must be a positive scalar");
-    BK_TRY(lambda_search(ctx, dQ, n, k, n, dvals, da, vals.data(), neig, opt->L, opt->U, -1.0, &lambda, &nprobes,
-                         out->lambda_trace, out->lambda_trace ? out->max_trace : 0));
+    BK_TRY(lambda_search(ctx, dQ + r0, nloc, k, n, dvals, da, vals.data(), neig, opt->L, opt->U, -1.0, &lambda, &nprobes,
+                         out->lambda_trace, out->lambda_trace ? out->max_trace : 0, comm, n));
   }
   timer.mark();                                                           // lambda
   {
@@ -265,10 +331,19 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
 
   // ---- step 4: coefficients, fitted values (:286-291) -----------------------------------------------
   double Le = 0.0;
-  BK_TRY(solveforc(ctx, dQ, n, k, n, dvals, da, lambda, dc, &Le));
-  if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
-  BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                              // yfitted = K c (full K)
-  if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
+  if (!comm) {
+    BK_TRY(solveforc(ctx, dQ, n, k, n, dvals, da, lambda, dc, &Le));
+    if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
+    BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                            // yfitted = K c (full K)
+    if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
+  } else {
+    // own rows of c and of K c (K symmetric: K[:, r0:r1)' c), one all-gather each; Le is a sum over the row blocks
+    if (nloc > 0) BK_TRY(solveforc(ctx, dQ + r0, nloc, k, n, dvals, da, lambda, dDloc, &Le));
+    BK_TRY(comm_all_reduce_host(comm, &Le, 1, COMM_SUM));
+    BK_TRY(comm_gather_rows(comm, dDloc, nloc, std::max<int64_t>(nloc, 1), 1, nb, n, dc, n));
+    if (nloc > 0) BK_TRY(gemv(ctx, 1, n, nloc, 1.0, dK, n, dc, 0.0, dSloc));
+    BK_TRY(comm_gather_rows(comm, dSloc, nloc, std::max<int64_t>(nloc, 1), 1, nb, n, dyhat, n));
+  }
   std::vector<double> coeffs(n), yhat(n);
   BK_HIP(hipMemcpyAsync(pin, dc, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));        // dyhat follows dc
   BK_HIP(hipStreamSynchronize(st));
@@ -296,9 +371,13 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
-        if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
-        BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_c, n));
-        if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
+        if (!comm) {
+          if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
+          BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_c, n));
+          if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
+        } else if (nloc > 0) {   // the column block V[:, r0:r1) = (Q diag(w)) Q[r0:r1, :]': kept sharded, no exchange
+          BK_TRY(gemm(ctx, 0, 1, n, nloc, k, sd2, dM, n, dQ + r0, n, 0.0, out->d_vcov_c, n));
+        }
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_c
@@ -308,9 +387,13 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
         for (int64_t i = 0; i < k; ++i) pin[i] = wv[i] * vals[i] * vals[i];
         BK_TRY(upload(ctx, dw, pin, k));
         BK_TRY(multdiag(ctx, dQ, n, k, n, dw, dM, n));
-        if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
-        BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_fitted, n));
-        if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
+        if (!comm) {
+          if (ctx->profile) BK_TRY(prof_begin(ctx, "vcov_syrk", (double)n * ((double)n + 1.0) * (double)k));
+          BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_fitted, n));
+          if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
+        } else if (nloc > 0) {
+          BK_TRY(gemm(ctx, 0, 1, n, nloc, k, sd2, dM, n, dQ + r0, n, 0.0, out->d_vcov_fitted, n));
+        }
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_fitted
@@ -341,9 +424,17 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
       }
     }
     BK_TRY(upload(ctx, dXe, pin, n * pd));
-    if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
-    BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n));
-    if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
+    if (!comm) {
+      if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
+      BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n));
+      if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
+    } else {
+      // own rows of D and S from the own column block, one all-gather of each (N x P')
+      const int64_t ldl = std::max<int64_t>(nloc, 1);
+      if (nloc > 0) BK_TRY(deriv_rows(ctx, dK, n, nloc, n, r0, dXe, pd, n, isbin.data(), dc, sigma, dDloc, ldl, dSloc, ldl));
+      BK_TRY(comm_gather_rows(comm, dDloc, nloc, ldl, pd, nb, n, dD, n));
+      BK_TRY(comm_gather_rows(comm, dSloc, nloc, ldl, pd, nb, n, dS, n));
+    }
     BK_HIP(hipStreamSynchronize(st));
     std::memcpy(pin, wv.data(), (size_t)k * sizeof(double));
     BK_TRY(upload(ctx, dw, pin, k));
@@ -424,6 +515,25 @@ int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t 
   timer.collect(out->phase_s);
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
+}
+
+int bigkrls_fit(bigkrls_ctx* ctx, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                const bigkrls_fit_options* opt, bigkrls_fit_outputs* out) {
+  return fit_impl(ctx, nullptr, h_X, h_y, n, p, opt, out);
+}
+
+int bigkrls_fit_dist_rows(bigkrls_comm* comm, int64_t n, const bigkrls_fit_options* opt, int64_t* r0, int64_t* r1) {
+  BK_REQUIRE(comm && opt && r0 && r1 && n > 1, "fit_dist_rows: bad arguments");
+  BK_REQUIRE(opt->struct_bytes == (int64_t)sizeof(bigkrls_fit_options), "fit_dist_rows: options struct size mismatch");
+  int mode = 0;
+  int64_t nb = 0;
+  return dist_plan(comm, n, opt, &mode, &nb, r0, r1);
+}
+
+int bigkrls_fit_dist(bigkrls_comm* comm, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                     const bigkrls_fit_options* opt, bigkrls_fit_outputs* out) {
+  BK_REQUIRE(comm && comm->ctx, "fit_dist: the communicator has no context");
+  return fit_impl(comm->ctx, comm, h_X, h_y, n, p, opt, out);
 }
 
 int bigkrls_predict(bigkrls_ctx* ctx, const double* h_X, int64_t n, int64_t p, const double* h_y,

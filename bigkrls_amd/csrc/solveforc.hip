@@ -296,7 +296,10 @@ __device__ __forceinline__ double sf_block_total(const double* __restrict__ part
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// grid (row blocks of 256, splits over k). consume_only: the launch that closes a chain (one workgroup).
+// grid (row blocks of ROWS rows, splits over k); the 256 threads of a workgroup are ROWS rows x 256 / ROWS groups
+// over the eigenpairs (a small N leaves most CUs idle with one row per thread: N = 20 000 is 79 workgroups of 256
+// rows, 625 of 32). consume_only: the launch that closes a chain (one workgroup).
+template <int ROWS>
 __global__ __launch_bounds__(256) void sf_probe_kernel(int n_rows, int k, int k_per_split,
                                                        const double* __restrict__ Q, int64_t ldq,
                                                        const double* __restrict__ d, const double* __restrict__ a,
@@ -304,9 +307,11 @@ __global__ __launch_bounds__(256) void sf_probe_kernel(int n_rows, int k, int k_
                                                        const double* __restrict__ le_in, double* __restrict__ le_out,
                                                        int n_le, double* __restrict__ pc, double* __restrict__ pg,
                                                        double* __restrict__ trace, int max_trace, int consume_only) {
+  constexpr int KG = 256 / ROWS;
   __shared__ double sw[SF_KC];
   __shared__ double swa[SF_KC];
   __shared__ double sh[4];
+  __shared__ double red[2][KG][ROWS];
   SfState s = *st_in;
   if (!s.done) {
     if (!s.fresh) {
@@ -322,7 +327,8 @@ __global__ __launch_bounds__(256) void sf_probe_kernel(int n_rows, int k, int k_
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *st_out = s;
   if (s.done || consume_only) return;
   const double lambda = s.cur;
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int r = threadIdx.x % ROWS, kg = threadIdx.x / ROWS;
+  const int row = blockIdx.x * ROWS + r;
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(k, kb + k_per_split);
   double c0 = 0.0, c1 = 0.0, g0 = 0.0, g1 = 0.0;
@@ -337,38 +343,53 @@ __global__ __launch_bounds__(256) void sf_probe_kernel(int n_rows, int k, int k_
     __syncthreads();
     if (row < n_rows) {
       const double* q = Q + row + (int64_t)base * ldq;
-      int j = 0;
+      int j = kg;
       // four eigenvector entries in flight per thread and pass
-      for (; j + 3 < cnt; j += 4) {
-        const double q0 = q[(int64_t)j * ldq], q1 = q[(int64_t)(j + 1) * ldq];
-        const double q2 = q[(int64_t)(j + 2) * ldq], q3 = q[(int64_t)(j + 3) * ldq];
+      for (; j + 3 * KG < cnt; j += 4 * KG) {
+        const double q0 = q[(int64_t)j * ldq], q1 = q[(int64_t)(j + KG) * ldq];
+        const double q2 = q[(int64_t)(j + 2 * KG) * ldq], q3 = q[(int64_t)(j + 3 * KG) * ldq];
         c0 += q0 * swa[j];
         g0 += q0 * q0 * sw[j];
-        c1 += q1 * swa[j + 1];
-        g1 += q1 * q1 * sw[j + 1];
-        c0 += q2 * swa[j + 2];
-        g0 += q2 * q2 * sw[j + 2];
-        c1 += q3 * swa[j + 3];
-        g1 += q3 * q3 * sw[j + 3];
+        c1 += q1 * swa[j + KG];
+        g1 += q1 * q1 * sw[j + KG];
+        c0 += q2 * swa[j + 2 * KG];
+        g0 += q2 * q2 * sw[j + 2 * KG];
+        c1 += q3 * swa[j + 3 * KG];
+        g1 += q3 * q3 * sw[j + 3 * KG];
       }
-      for (; j < cnt; ++j) {
+      for (; j < cnt; j += KG) {
         const double q0 = q[(int64_t)j * ldq];
         c0 += q0 * swa[j];
         g0 += q0 * q0 * sw[j];
       }
     }
   }
+  double cs = c0 + c1, gs = g0 + g1;
+  if (KG > 1) {   // the groups' partial sums of a row, added in group order
+    red[0][kg][r] = cs;
+    red[1][kg][r] = gs;
+    __syncthreads();
+    if (kg == 0) {
+      cs = red[0][0][r];
+      gs = red[1][0][r];
+#pragma unroll
+      for (int q = 1; q < KG; ++q) {
+        cs += red[0][q][r];
+        gs += red[1][q][r];
+      }
+    }
+  }
   if (gridDim.y > 1) {
-    if (row < n_rows) {
-      pc[(int64_t)blockIdx.y * n_rows + row] = c0 + c1;
-      pg[(int64_t)blockIdx.y * n_rows + row] = g0 + g1;
+    if (row < n_rows && kg == 0) {
+      pc[(int64_t)blockIdx.y * n_rows + row] = cs;
+      pg[(int64_t)blockIdx.y * n_rows + row] = gs;
     }
     return;
   }
   double t = 0.0;
-  if (row < n_rows) {
-    const double r = (c0 + c1) / (g0 + g1);
-    t = r * r;
+  if (row < n_rows && kg == 0) {
+    const double rr = cs / gs;
+    t = rr * rr;
   }
   t = wave_sum_sf(t);
   __syncthreads();
@@ -404,30 +425,35 @@ __global__ __launch_bounds__(256) void sf_probe_finish_kernel(int n_rows, int sp
 int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
                   const double* d, const double* a, const double* h_vals_all, int64_t n_vals,
                   double L, double U, double tol, double* h_lambda, int64_t* h_nprobes,
-                  double* h_trace, int64_t max_trace) {
+                  double* h_trace, int64_t max_trace, bigkrls_comm* comm, int64_t n_total) {
   BK_REQUIRE(h_lambda, "lambda_search: null output");
-  BK_REQUIRE(n > 0 && k > 0 && n < (1ll << 31) && k < (1ll << 31), "lambda_search: bad dimensions");
-  BK_REQUIRE(Q && d && a, "lambda_search: null pointer");
-  if (tol <= 0.0) tol = 1e-3 * (double)n;  // R/bigKRLS_Rcpp_functions.R:11-12
+  if (n_total <= 0) n_total = n;
+  BK_REQUIRE(n >= 0 && n_total > 0 && k > 0 && n_total < (1ll << 31) && k < (1ll << 31), "lambda_search: bad dimensions");
+  BK_REQUIRE((Q || n == 0) && d && a, "lambda_search: null pointer");
+  BK_REQUIRE(comm || n == n_total, "lambda_search: a row block needs a communicator");
+  if (tol <= 0.0) tol = 1e-3 * (double)n_total;  // R/bigKRLS_Rcpp_functions.R:11-12
   if (L < 0.0 || U < 0.0) {
     double l0, u0;
-    BK_TRY(lambda_bounds(h_vals_all, n_vals, n, &l0, &u0));
+    BK_TRY(lambda_bounds(h_vals_all, n_vals, n_total, &l0, &u0));
     if (L < 0.0) L = l0;
     if (U < 0.0) U = u0;
   }
   hipStream_t st = ctx->stream;
-  const int rb = (int)((n + 255) / 256);
+  const int rows = (n <= 32 * 16384) ? 32 : 256;          // rows per workgroup of the probe kernel
+  const int rb = (int)std::max<int64_t>((n + rows - 1) / rows, 1);
+  const int rbf = (int)std::max<int64_t>((n + 255) / 256, 1);   // row blocks of the finish kernel (k split over workgroups)
   int splits = (1024 + rb - 1) / rb;
   const int max_splits = (int)((k + SF_KC - 1) / SF_KC);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int kps = (int)(((k + splits - 1) / splits + SF_KC - 1) / SF_KC * SF_KC);
   splits = (int)((k + kps - 1) / kps);
+  const int nle = splits > 1 ? rbf : rb;   // partial losses a probe leaves behind
   constexpr int CHAIN = 48;        // probe launches per chain (a search takes 15-40)
   constexpr int DEV_TRACE = 512;   // probes recorded on the device
   // workspace: state[2], le[2][rb], trace[2 DEV_TRACE], pc / pg [splits n]
   const int64_t st_d = (2 * (int64_t)sizeof(SfState) + 7) / 8;
-  const int64_t nd = st_d + 2 * rb + 2 * DEV_TRACE + (splits > 1 ? 2 * (int64_t)splits * n : 0) + 8;
+  const int64_t nd = st_d + 2 * rb + 2 * DEV_TRACE + (splits > 1 ? 2 * (int64_t)splits * n : 0) + 16;
   void* p = nullptr;
   BK_TRY(ws_get(ctx, SLOT_SOLVE_PART, nd * sizeof(double), &p));
   SfState* dstate = (SfState*)p;
@@ -435,6 +461,7 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64
   double* dtrace = le + 2 * rb;
   double* pc = dtrace + 2 * DEV_TRACE;
   double* pg = pc + (splits > 1 ? (int64_t)splits * n : 0);
+  double* lsum = pg + (splits > 1 ? (int64_t)splits * n : 0);   // [2]: the all-reduced loss of a probe (row-block search)
   // initial state (:38-39): X1 <- L + .381966 (U - L); X2 <- U - .381966 (U - L)
   double* hp = nullptr;
   const int64_t hp_d = st_d + 2 * DEV_TRACE;
@@ -462,15 +489,25 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64
       const bool close = (i == CHAIN);
       const bool samp = ctx->profile && chain == 0 && i == 1;
       if (samp) BK_TRY(prof_begin(ctx, "solveforc_probe", 8.0 * (double)n * (double)k));
-      hipLaunchKernelGGL(sf_probe_kernel, close ? dim3(1, 1) : dim3(rb, splits), dim3(256), 0, st, (int)n, (int)k, kps, Q, ldq,
-                         d, a, (const SfState*)&dstate[cur], &dstate[cur ^ 1], (const double*)(le + (cur ^ 1) * rb),
-                         le + cur * rb, rb, pc, pg, dtrace, DEV_TRACE, close ? 1 : 0);
+      // (a row-block search consumes the loss summed over the ranks: one double)
+      const double* le_prev = comm ? lsum + (cur ^ 1) : le + (cur ^ 1) * rb;
+      auto kern = rows == 32 ? sf_probe_kernel<32> : sf_probe_kernel<256>;
+      hipLaunchKernelGGL(kern, close ? dim3(1, 1) : dim3(rb, splits), dim3(256), 0, st, (int)n, (int)k, kps, Q, ldq,
+                         d, a, (const SfState*)&dstate[cur], &dstate[cur ^ 1], le_prev, le + cur * rb, comm ? 1 : nle,
+                         pc, pg, dtrace, DEV_TRACE, close ? 1 : 0);
       if (samp) BK_TRY(prof_end(ctx, "solveforc_probe"));
       BK_CHECK_LAUNCH();
       if (!close && splits > 1) {
-        hipLaunchKernelGGL(sf_probe_finish_kernel, dim3(rb), dim3(256), 0, st, (int)n, splits, (const double*)pc,
+        hipLaunchKernelGGL(sf_probe_finish_kernel, dim3(rbf), dim3(256), 0, st, (int)n, splits, (const double*)pc,
                            (const double*)pg, (const SfState*)&dstate[cur ^ 1], le + cur * rb);
         BK_CHECK_LAUNCH();
+      }
+      if (comm && !close) {
+        // the probe's loss over all rows: this rank's sum, then one all-reduce of a scalar,
+        // stream-ordered like the launches around it
+        hipLaunchKernelGGL(sf_sum_kernel, dim3(1), dim3(256), 0, st, nle, (const double*)(le + cur * rb), lsum + cur);
+        BK_CHECK_LAUNCH();
+        BK_TRY(comm_all_reduce(comm, lsum + cur, 1, COMM_SUM));
       }
     }
     // the closing launch consumed the chain's last loss without starting a probe: a search that is not done

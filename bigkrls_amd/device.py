@@ -70,11 +70,13 @@ class Context:
             raise RuntimeError("bigkrls_amd needs a HIP device (MI355X); there is no CPU fallback")
         self.torch = torch
         self.device_index = torch.cuda.current_device() if device is None else int(device)
-        torch.cuda.set_device(self.device_index)
         self.device = torch.device("cuda", self.device_index)
-        self.stream = torch.cuda.Stream(self.device) if own_stream else torch.cuda.current_stream(self.device)
-        h = C.c_void_p()
-        _lib.call("bigkrls_ctx_create_on_stream", self.device_index, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        # (the process-wide current device is left as the caller had it: a context for GPU 3 must not redirect
+        #  the caller's later default_context() or plain torch code to GPU 3)
+        with torch.cuda.device(self.device_index):
+            self.stream = torch.cuda.Stream(self.device) if own_stream else torch.cuda.current_stream(self.device)
+            h = C.c_void_p()
+            _lib.call("bigkrls_ctx_create_on_stream", self.device_index, C.c_void_p(self.stream.cuda_stream), C.byref(h))
         self.handle = h
         self._events = []
         self._stage = None

@@ -383,6 +383,53 @@ int bigkrls_predict(bigkrls_ctx* ctx, const double* h_X, int64_t n, int64_t p, c
                     const double* d_vcov_c, double neffective,
                     double* h_predicted, double* h_se_pred, double* d_newdataK, double* d_vcov_pred);
 
+/* =============================================================================
+ * Multi-GPU: one process per GPU, the collectives inside the library (the context's
+ * "device list, streams, RCCL comm"; section 8(e): the partitioning). The reference's parallel path is driven from R
+ * (PSOCK workers, R/bigKRLS.R:337-363); here the R shim starts one process per GPU, distributes a unique id and
+ * every process calls bigkrls_fit_dist with the same X, y and options.
+ * ========================================================================== */
+typedef struct bigkrls_comm bigkrls_comm;
+#define BIGKRLS_UNIQUE_ID_BYTES 128
+/* Rank 0: a fresh id (ncclGetUniqueId) for the caller to hand to every rank (sockets, MPI, a file, ...). */
+int bigkrls_comm_unique_id(void* id_out_128_bytes);
+/* Every rank, concurrently: ncclCommInitRank on the context's device. RCCL (librccl.so) is opened at run time; a
+ * missing library gives BIGKRLS_ENODEVICE. nranks == 1 is valid (the collectives then run on one GPU). */
+int bigkrls_comm_create(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const void* unique_id_128_bytes,
+                        bigkrls_comm** comm);
+/* The same rank object over caller-supplied collectives instead of RCCL: every callback receives DEVICE pointers to
+ * doubles (the library has synchronised its stream before the call and expects the result in place at return) and
+ * returns 0 on success. op: 0 = sum, 1 = min. Used by the tests to run several ranks on ONE GPU with host-staged
+ * collectives; ctx may be NULL for a table that is only passed to bigkrls_comm_check. */
+typedef struct bigkrls_collectives {
+  int64_t struct_bytes;   /* sizeof(bigkrls_collectives); checked */
+  void* user;
+  int (*all_reduce)(void* user, double* buf, int64_t count, int32_t op);
+  int (*all_gather)(void* user, const double* send, double* recv, int64_t count_per_rank);
+  int (*broadcast)(void* user, double* buf, int64_t count, int32_t root);
+} bigkrls_collectives;
+int bigkrls_comm_create_callbacks(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const bigkrls_collectives* table,
+                                  bigkrls_comm** comm);
+int bigkrls_comm_destroy(bigkrls_comm* comm);
+int bigkrls_comm_rank(bigkrls_comm* comm, int32_t* rank, int32_t* nranks);
+/* Plumbing check: one all-reduce (sum) of buf[0 .. count), one all-reduce (min) of buf[count .. 2 count), one
+ * all-gather of buf[2 count .. 3 count) into buf[4 count .. (4 + nranks) count) and one broadcast from the last rank
+ * of buf[3 count .. 4 count); buf is whatever memory the collectives accept (device for RCCL). */
+int bigkrls_comm_check(bigkrls_comm* comm, double* buf, int64_t count);
+/* The rows [*r0, *r1) this rank owns in a bigkrls_fit_dist call with these sizes and options (blocks of
+ * ceil(n / nranks) rows, a multiple of 64 where the dense eigensolver's stage 1 is partitioned): the caller sizes
+ * the device outputs with it. */
+int bigkrls_fit_dist_rows(bigkrls_comm* comm, int64_t n, const bigkrls_fit_options* options, int64_t* r0, int64_t* r1);
+/* bigkrls_fit over the ranks of `comm` (same h_X, h_y, options on every rank): rank r builds and keeps the column
+ * block K[:, r0:r1) only -- K is never gathered --, the eigensolver is the block Lanczos with sharded K B_j products
+ * (Neig << N) or the dense path with stage 1 partitioned by column blocks, lambda search / coefficients / fitted
+ * values / variance matrices / marginal effects work on the row block with one all-reduce or all-gather each.
+ * Every rank receives the same small host outputs; the device outputs d_K, d_vcov_c, d_vcov_fitted are this rank's
+ * COLUMN blocks (n x (r1 - r0), ld n). BIGKRLS_DIST_EIGEN=krylov|dense|replicated overrides the choice of the
+ * eigensolver (development / tests). */
+int bigkrls_fit_dist(bigkrls_comm* comm, const double* h_X, const double* h_y, int64_t n, int64_t p,
+                     const bigkrls_fit_options* options, bigkrls_fit_outputs* out);
+
 #ifdef __cplusplus
 }
 #endif

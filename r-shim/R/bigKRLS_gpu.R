@@ -100,6 +100,44 @@ bigKRLS <- function(y = NULL, X = NULL, sigma = NULL, derivative = TRUE, which.d
   w
 }
 
+# ---- multi-GPU: one R process per GPU, the partitioned fit inside the library (bigkrls_fit_dist) ---------------------
+# The reference's Ncores starts a PSOCK cluster for the derivative columns (R/bigKRLS.R:337-363); here a PSOCK cluster
+# of `ngpus` processes, process i on GPU i - 1 as rank i - 1: K is built, decomposed and used in row blocks and never
+# gathered. Every rank computes the same base R outputs; the one of rank 0 is returned (the N x N matrices stay
+# sharded on the GPUs and are dropped with the workers).
+.bigkrls_rank <- function(rank, ngpus, id, y, X, args) {
+  ctx <- DevContext(as.integer(rank))
+  comm <- CommCreate(ctx, as.integer(ngpus), as.integer(rank), id)
+  on.exit(CommDestroy(comm))
+  unset <- function(v, d) if (is.null(v)) d else as.double(v)
+  BigKRLSFitDist(comm, X, as.double(y), unset(args$sigma, 0), unset(args$lambda, 0), unset(args$L, -1),
+                 unset(args$U, -1), unset(args$eigtrunc, -1), unset(args$Neig, 0), args$derivative, args$vcov.est,
+                 args$acf, args$which.derivatives, NULL, NULL, NULL)
+}
+
+bigKRLS_multi_gpu <- function(y, X, ngpus, sigma = NULL, derivative = TRUE, which.derivatives = NULL,
+                              vcov.est = TRUE, Neig = NULL, eigtrunc = NULL, lambda = NULL, L = NULL, U = NULL,
+                              acf = FALSE) {
+  stopifnot(is.matrix(X), ngpus >= 1)
+  storage.mode(X) <- "double"
+  args <- list(sigma = sigma, derivative = derivative, which.derivatives = which.derivatives, vcov.est = vcov.est,
+               Neig = Neig, eigtrunc = eigtrunc, lambda = lambda, L = L, U = U, acf = acf)
+  cl <- parallel::makePSOCKcluster(ngpus)
+  on.exit(parallel::stopCluster(cl))
+  parallel::clusterEvalQ(cl, library(bigKRLS))
+  id <- CommUniqueId()
+  res <- parallel::clusterApply(cl, 0:(ngpus - 1), .bigkrls_rank, ngpus = ngpus, id = id, y = y, X = X, args = args)
+  w <- res[[1]]
+  w[["X"]] <- X
+  w[["y"]] <- matrix(as.double(y), ncol = 1)
+  w[["has.big.matrices"]] <- FALSE
+  w[["which.derivatives"]] <- which.derivatives
+  w[["xlabs"]] <- if (is.null(colnames(X))) paste0("x", 1:ncol(X)) else colnames(X)
+  w[["derivative.call"]] <- derivative
+  class(w) <- "bigKRLS"
+  w
+}
+
 predict.bigKRLS <- function(object, newdata, se.pred = FALSE, correct_SE = TRUE, ytest = NULL, device = 0L, ...) {
   if (!inherits(object, "bigKRLS")) stop("Object not of class 'bigKRLS'")
   if (se.pred && is.null(object$vcov.est.c))

@@ -108,11 +108,10 @@ void HostToDev(SEXP ctx, SEXP d, NumericMatrix m) {               // as.big.matr
 // [[Rcpp::export]]
 void DevFree(SEXP ctx, SEXP d) { chk(bigkrls_dev_free(XPtr<bigkrls_ctx>(ctx), R_ExternalPtrAddr(d))); R_ClearExternalPtr(d); }
 
-// replaces the body of bigKRLS(), R/bigKRLS.R:175-470
-// [[Rcpp::export]]
-List BigKRLSFit(SEXP ctx, NumericMatrix X, NumericVector y, double sigma, double lambda, double L, double U,
-                double eigtrunc, double Neig, bool derivative, bool vcov_est, bool acf,
-                Nullable<IntegerVector> which_derivatives, SEXP dK, SEXP dVc, SEXP dVf) {
+// the fit on one GPU (comm == NULL: bigkrls_fit) or over the ranks of a communicator (bigkrls_fit_dist)
+static List fit_call(SEXP ctx, SEXP comm, NumericMatrix X, NumericVector y, double sigma, double lambda, double L, double U,
+                     double eigtrunc, double Neig, bool derivative, bool vcov_est, bool acf,
+                     Nullable<IntegerVector> which_derivatives, SEXP dK, SEXP dVc, SEXP dVf) {
   const int64_t n = X.nrow(), p = X.ncol();
   std::vector<int64_t> which;
   bigkrls_fit_options o = {sizeof(o), sigma, lambda, L, U, eigtrunc, (int64_t)Neig,
@@ -129,15 +128,53 @@ List BigKRLSFit(SEXP ctx, NumericMatrix X, NumericVector y, double sigma, double
   r.eigenvalues = vals.begin(); r.coeffs = coeffs.begin(); r.yfitted = yfitted.begin();
   r.derivatives = D.begin(); r.avgderivatives = avg.begin(); r.var_avgderivatives = var.begin();
   r.binaryindicator = isbin.begin(); r.lambda_trace = trace.begin(); r.max_trace = 256;
-  r.d_K = (double*)R_ExternalPtrAddr(dK);
-  r.d_vcov_c = vcov_est ? (double*)R_ExternalPtrAddr(dVc) : nullptr;
-  r.d_vcov_fitted = vcov_est ? (double*)R_ExternalPtrAddr(dVf) : nullptr;
-  chk(bigkrls_fit(XPtr<bigkrls_ctx>(ctx), X.begin(), y.begin(), n, p, &o, &r));   // R's message text on bad data
+  r.d_K = Rf_isNull(dK) ? nullptr : (double*)R_ExternalPtrAddr(dK);
+  r.d_vcov_c = (vcov_est && !Rf_isNull(dVc)) ? (double*)R_ExternalPtrAddr(dVc) : nullptr;
+  r.d_vcov_fitted = (vcov_est && !Rf_isNull(dVf)) ? (double*)R_ExternalPtrAddr(dVf) : nullptr;
+  if (Rf_isNull(comm)) chk(bigkrls_fit(XPtr<bigkrls_ctx>(ctx), X.begin(), y.begin(), n, p, &o, &r));   // R's message text on bad data
+  else chk(bigkrls_fit_dist(XPtr<bigkrls_comm>(comm), X.begin(), y.begin(), n, p, &o, &r));
   return List::create(_["K.eigenvalues"] = vals, _["lastkeeper"] = (double)r.lastkeeper, _["coeffs"] = coeffs,
                       _["yfitted"] = yfitted, _["lambda"] = r.lambda, _["sigma"] = r.sigma, _["R2"] = r.R2,
                       _["R2AME"] = r.R2AME, _["Looe"] = r.Looe, _["Neffective"] = r.Neffective,
                       _["Neffective.acf"] = r.Neffective_acf, _["derivatives"] = D, _["avgderivatives"] = avg,
                       _["var.avgderivatives"] = var, _["binaryindicator"] = isbin);
+}
+
+// replaces the body of bigKRLS(), R/bigKRLS.R:175-470
+// [[Rcpp::export]]
+List BigKRLSFit(SEXP ctx, NumericMatrix X, NumericVector y, double sigma, double lambda, double L, double U,
+                double eigtrunc, double Neig, bool derivative, bool vcov_est, bool acf,
+                Nullable<IntegerVector> which_derivatives, SEXP dK, SEXP dVc, SEXP dVf) {
+  return fit_call(ctx, R_NilValue, X, y, sigma, lambda, L, U, eigtrunc, Neig, derivative, vcov_est, acf, which_derivatives,
+                  dK, dVc, dVf);
+}
+
+// ---- multi-GPU: one R process per GPU (the reference starts PSOCK workers for its derivative loop,
+//      R/bigKRLS.R:337-363); the collectives run inside the library over RCCL -----------------------------------
+// [[Rcpp::export]]
+RawVector CommUniqueId() {                                        // rank 0; hand the bytes to every rank
+  RawVector id(BIGKRLS_UNIQUE_ID_BYTES);
+  chk(bigkrls_comm_unique_id(id.begin()));
+  return id; }
+// [[Rcpp::export]]
+SEXP CommCreate(SEXP ctx, int nranks, int rank, RawVector id) {   // every rank, concurrently (ncclCommInitRank)
+  bigkrls_comm* c; chk(bigkrls_comm_create(XPtr<bigkrls_ctx>(ctx), nranks, rank, id.begin(), &c));
+  return XPtr<bigkrls_comm>(c, false); }
+// [[Rcpp::export]]
+void CommDestroy(SEXP comm) { chk(bigkrls_comm_destroy(XPtr<bigkrls_comm>(comm))); R_ClearExternalPtr(comm); }
+// [[Rcpp::export]]
+NumericVector FitDistRows(SEXP comm, double n, double Neig) {      // the rows [r0, r1) this rank owns (0-based)
+  bigkrls_fit_options o = {sizeof(o), 0, 0, -1, -1, -1, (int64_t)Neig, 1, 1, 0, 0, nullptr, 0};
+  int64_t r0 = 0, r1 = 0;
+  chk(bigkrls_fit_dist_rows(XPtr<bigkrls_comm>(comm), (int64_t)n, &o, &r0, &r1));
+  return NumericVector::create((double)r0, (double)r1); }
+// [[Rcpp::export]]
+List BigKRLSFitDist(SEXP comm, NumericMatrix X, NumericVector y, double sigma, double lambda, double L, double U,
+                    double eigtrunc, double Neig, bool derivative, bool vcov_est, bool acf,
+                    Nullable<IntegerVector> which_derivatives, SEXP dKcols, SEXP dVcCols, SEXP dVfCols) {
+  // dKcols, dVcCols, dVfCols: this rank's column blocks (n x (r1 - r0) device matrices) or NULL
+  return fit_call(R_NilValue, comm, X, y, sigma, lambda, L, U, eigtrunc, Neig, derivative, vcov_est, acf,
+                  which_derivatives, dKcols, dVcCols, dVfCols);
 }
 
 // replaces the body of predict.bigKRLS(), R/bigKRLS.R:590-621

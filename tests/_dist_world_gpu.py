@@ -1,10 +1,11 @@
-"""The row-block path (bigkrls_amd.dist) with the HIP backend at WORLD_SIZE > 1 on ONE GPU.
+"""bigkrls_fit_dist at WORLD_SIZE > 1 on ONE GPU.
 
-RCCL refuses two ranks on one device, and this pool hands out single-GPU boxes, so the multi-rank code of
-the HIP backend (column blocks with offsets, the partitioned stage 1, the split back-transform) is driven
-here through a gloo group: every rank is its own process with its own context on device 0, collectives on
-device tensors are staged through host memory by the shim below (test only; the product path uses RCCL).
-Checks every rank's result against the single-process fit.
+RCCL refuses two ranks on one device, and this pool hands out single-GPU boxes, so the multi-rank code of the
+library (column blocks with offsets, the partitioned stage 1, the split back-transform, the sharded block Lanczos,
+the row-block lambda search) is driven here through its callback table (bigkrls_comm_create_callbacks): every
+rank is its own process with its own context on device 0, the collectives stage the device buffers through host
+memory and a gloo group (bigkrls_amd.dist.comm_callbacks; test only, the product path uses RCCL).
+Checks every rank's result -- and its column blocks of K and vcov.est.c -- against the single-process fit.
 
     python tests/_dist_world_gpu.py [N] [P] [WORLD] [--krylov NEIG]
 
@@ -34,42 +35,6 @@ def launcher():
     sys.exit(rc)
 
 
-class HostStagedDist:
-    """torch.distributed with device tensors staged through the host (gloo)."""
-
-    def __init__(self, dist, torch):
-        self._d, self._t = dist, torch
-        self.ReduceOp = dist.ReduceOp
-
-    def is_initialized(self):
-        return self._d.is_initialized()
-
-    def get_rank(self):
-        return self._d.get_rank()
-
-    def get_world_size(self):
-        return self._d.get_world_size()
-
-    def barrier(self):
-        self._d.barrier()
-
-    def broadcast(self, t, src=0):
-        h = t.detach().cpu().contiguous()
-        self._d.broadcast(h, src=src)
-        t.copy_(h.view(t.shape))
-
-    def all_reduce(self, t, op=None):
-        h = t.detach().cpu().contiguous()
-        self._d.all_reduce(h, op=op if op is not None else self._d.ReduceOp.SUM)
-        t.copy_(h.view(t.shape))
-
-    def all_gather_into_tensor(self, out, inp):
-        hi = inp.detach().cpu().contiguous()
-        ho = self._t.empty(out.shape, dtype=out.dtype)
-        self._d.all_gather_into_tensor(ho, hi)
-        out.copy_(ho)
-
-
 def worker():
     sys.path.insert(0, ROOT)
     import time
@@ -88,14 +53,14 @@ def worker():
         neig = int(sys.argv[sys.argv.index("--krylov") + 1])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    staged = HostStagedDist(dist, torch)
-    bkdist._torch_dist = lambda: (torch, staged)          # see bigkrls_amd/dist.py
     ctx = bk.Context(0)
+    comm = bkdist.get_comm(ctx, "host")                   # bigkrls_comm_create_callbacks: collectives staged through gloo
+    assert (comm.world, comm.rank, comm.kind) == (world, rank, "callbacks")
     X, y = synth(n, p, 103)
     kw = dict(Neig=neig) if neig else {}
     T = {}
     t0 = time.perf_counter()
-    out = bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=T, keep_outputs=True, **kw)
+    out = bkdist.bigKRLS_dist(y, X, comm=comm, timings=T, keep_outputs=True, **kw)
     ctx.sync()
     dt = time.perf_counter() - t0
     one = bk.bigKRLS(y, X, ctx=ctx, **kw)
@@ -113,10 +78,17 @@ def worker():
         "K.eigenvalues[:lastkeeper]": rel(np.asarray(out["K.eigenvalues"])[: out["lastkeeper"]],
                                           np.asarray(one["K.eigenvalues"])[: one["lastkeeper"]]),
     }
+    r0, r1 = out["rows"]
+    if r1 > r0:
+        checks["K.cols"] = rel(out["K.cols"].to_numpy()[:, : r1 - r0], one["K"].to_numpy()[:, r0:r1] if hasattr(one["K"], "to_numpy") else one["K"][:, r0:r1])
+        vc = one["vcov.est.c"]
+        vc = vc.to_numpy() if hasattr(vc, "to_numpy") else vc
+        checks["vcov.est.c.cols"] = rel(out["vcov.est.c.cols"].to_numpy()[:, : r1 - r0], vc[:, r0:r1])
     ok = out["lastkeeper"] == one["lastkeeper"] and all(v < 1e-7 for v in checks.values())
     print(f"rank {rank}/{world} N={n} P={p} neig={neig}: {dt:.2f} s lastkeeper {out['lastkeeper']} vs {one['lastkeeper']} "
           + " ".join(f"{k}={v:.1e}" for k, v in checks.items()) + (" OK" if ok else " MISMATCH"), flush=True)
     dist.barrier()
+    bkdist.release_comms()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 

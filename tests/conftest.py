@@ -38,8 +38,12 @@ def pytest_sessionstart(session):
     import tempfile
     for name, args in WORLD_CASES.items():
         log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
+        # Seven rank processes share the one GPU with this session: the persistent kernels of the eigensolver spin on
+        # messages between workgroups that must be co-resident, which nothing guarantees here, and a fired watchdog
+        # cannot be replayed in the partitioned stage 1 -- the rank processes use the launch-per-step kernels.
+        env = dict(os.environ, BIGKRLS_PQ="steps", BIGKRLS_BC="wavefront")
         proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_world_gpu.py")] + args,
-                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env)
         _world_runs[name] = (proc, log.name)
 
 

@@ -190,20 +190,31 @@ def test_fit_medium_n2000(ctx, monkeypatch, path):
     assert_fit_parity(out, ref)
 
 
-def test_dist_path_world1_hip_backend(ctx):
-    """bigkrls_amd.dist with the HIP backend on one GPU (no process group): every
-    backend entry point of the row-block path against the single-GPU fit and the oracle."""
+def test_dist_path_world1_rccl_communicator(ctx):
+    """bigkrls_fit_dist on one GPU through a one-rank RCCL communicator (ncclCommInitRank inside the library, no
+    process group): the row-block code path with every collective issued -- against the oracle, and the sharded
+    N x N outputs (this rank's column blocks = everything) against the oracle's matrices."""
     import bigkrls_amd as bk
     from bigkrls_amd import dist as bkdist
     X, y = orc.synth(700, 5, 48, binary_last=True)
     ref = orc.fit(y, X, literal=False)
-    out = bkdist.bigKRLS_dist(y, X, ctx=ctx)
+    comm = bkdist.get_comm(ctx, "rccl")
+    assert (comm.world, comm.rank, comm.kind) == (1, 0, "rccl")
+    tr = []
+    out = bkdist.bigKRLS_dist(y, X, comm=comm, trace=tr)
     assert out["rows"] == (0, 700)
     assert_fit_parity(out, ref, squares=False)
-    sd2 = orc.r_sd(y) ** 2
-    assert rel(out["K.cols"].cpu().numpy().T, ref["K"]) < 1e-12
-    assert rel(out["vcov.est.c.cols"].cpu().numpy().T, ref["vcov.est.c"]) < TOL
-    assert rel(out["vcov.est.fitted.cols"].cpu().numpy().T, ref["vcov.est.fitted"]) < TOL
+    assert len(tr) > 5 and abs(tr[-1][0] - out["lambda"]) < 0.5 * out["lambda"]
+    assert rel(out["K.cols"].to_numpy(), ref["K"]) < 1e-12
+    assert rel(out["vcov.est.c.cols"].to_numpy(), ref["vcov.est.c"]) < TOL
+    assert rel(out["vcov.est.fitted.cols"].to_numpy(), ref["vcov.est.fitted"]) < TOL
+    # the same through the callback table (host-staged collectives, one rank): identical small outputs
+    cb = bkdist.bigKRLS_dist(y, X, ctx=ctx, collectives="host")
+    for k in ("coeffs", "derivatives", "var.avgderivatives", "K.eigenvalues"):
+        assert np.array_equal(np.asarray(cb[k]), np.asarray(out[k])), k
+    assert cb["lambda"] == out["lambda"]
+    lean = bkdist.bigKRLS_dist(y, X, comm=comm, keep_outputs=False)      # nothing N x N handed back
+    assert "K.cols" not in lean and np.array_equal(lean["coeffs"], out["coeffs"])
 
 
 @pytest.mark.gpu
@@ -308,9 +319,8 @@ def test_eigen_column_partition_sums_to_full():
 
 @pytest.mark.gpu
 def test_dist_path_sharded_block_lanczos_world1(ctx):
-    """The row-sharded block-Lanczos eigen path of bigkrls_amd.dist (SURVEY 8(e) "Eigen, partial") with
-    the HIP backend on one GPU: same fit as the single-GPU library (which runs its own C++ block
-    Lanczos or the dense path) for Neig << N."""
+    """bigkrls_fit_dist with the block Lanczos whose K B_j products are sharded by row block (SURVEY 8(e) "Eigen,
+    partial"), one rank: the same fit as bigkrls_fit for Neig << N."""
     import bigkrls_amd as bk
     from bigkrls_amd import dist as bkdist
     X, y = orc.synth(4500, 6, 52)
@@ -349,40 +359,31 @@ def test_crossvalidate_fold_parallel_contexts(ctx):
 
 @pytest.mark.gpu
 def test_dist_dense_sharded_eigen_world1_hip_backend(ctx):
-    """The dense eigensolver with stage 1 driven panel by panel through bigkrls_dev_s1_* (the
-    multi-GPU code path of bigkrls_amd.dist, SURVEY 8(e) "Eigen, dense"), HIP backend, one GPU, no
-    process group: eigenpairs against the single-call library, the fit against bigKRLS()."""
-    import torch
+    """bigkrls_fit_dist with the dense eigensolver whose stage 1 is partitioned by column blocks (SURVEY 8(e) "Eigen,
+    dense"; one rank: the broadcast / all-gather per panel, the symmetric update of the diagonal block, the split
+    back-transform), Neig = N and Neig < N, and the replicated decomposition: against bigKRLS() on the same GPU."""
     import bigkrls_amd as bk
-    from bigkrls_amd import dist as bkdist, ops
+    from bigkrls_amd import dist as bkdist
     n, p = 1500, 6
     X, y = orc.synth(n, p, 53)
-    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
-    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
-    be = bkdist.HipBackend(ctx)
-    nb, parts = bkdist.partition(n, 1, bkdist.S1_B)
-    for neig, trunc in ((n, 0.001), (100, -1.0)):
-        vals, nv, Q, _ = bkdist.eigen_dense_dist(be, torch, torch.distributed, K.t.clone(), n, 0, 1, nb, neig, trunc)
-        ref = ops.bEigen(K, neig, trunc)
-        assert nv == ref.lastkeeper and rel(vals, ref.values) < 1e-12
-        Qd = bk.device.DeviceMatrix(ctx, Q.contiguous())
-        R = ops.gemm(False, False, K, Qd).to_numpy() - Qd.to_numpy() * vals[:nv]
-        G = ops.gemm(True, False, Qd, Qd).to_numpy()
-        assert np.abs(R).max() / vals[0] < 1e-11 and np.abs(G - np.eye(nv)).max() < 1e-11
     one = bk.bigKRLS(y, X, ctx=ctx)
-    out = bkdist.bigKRLS_dist(y, X, ctx=ctx)
-    assert out["lastkeeper"] == one["lastkeeper"] and abs(out["lambda"] - one["lambda"]) <= 1e-9 * one["lambda"]
-    for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives", "K.eigenvalues"):
-        assert rel(out[k], one[k]) < 1e-8, k
+    for mode, neig in (("dense", None), ("dense", 100), ("replicated", None)):
+        kw = dict(Neig=neig) if neig else {}
+        ref1 = one if neig is None else bk.bigKRLS(y, X, ctx=ctx, **kw)
+        out = bkdist.bigKRLS_dist(y, X, ctx=ctx, eigen_mode=mode, **kw)
+        assert out["lastkeeper"] == ref1["lastkeeper"] and abs(out["lambda"] - ref1["lambda"]) <= 1e-9 * ref1["lambda"]
+        for k in ("coeffs", "yfitted", "derivatives", "var.avgderivatives", "K.eigenvalues"):
+            assert rel(out[k], ref1[k]) < 1e-8, (mode, neig, k)
+        assert rel(out["vcov.est.c.cols"].to_numpy(), ref1["vcov.est.c"]) < 1e-8
 
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_dist_paths_under_a_world1_rccl_group(ctx):
-    """`nccl` (== RCCL) process group of size 1 on the GPU: every collective of the row-block fit --
-    broadcast of the panel strips, all-gather of A22 V, all-gather of the eigenvector column blocks,
-    all-gather of the Lanczos blocks, the all-reduces of the lambda search -- is issued through RCCL
-    (dist.py runs them whenever a group exists). Dense-sharded and block-Lanczos eigen paths."""
+    """Under a torch.distributed `nccl` group of size 1: the communicator is built from the group (unique id from
+    rank 0, ncclCommInitRank in the library) and every collective of the fit -- broadcast of the panel strips,
+    all-gather of A22 V, of the eigenvector column blocks, of the Lanczos blocks, the all-reduces of the lambda
+    search -- is issued by the library through RCCL. Dense-sharded, block-Lanczos and replicated eigen paths."""
     import socket
     import torch
     import torch.distributed as dist
@@ -405,6 +406,7 @@ def test_dist_paths_under_a_world1_rccl_group(ctx):
         rp = bkdist.bigKRLS_dist(y, X, ctx=ctx, eigen_mode="replicated")   # K all-gathered, Q by all-reduce
         assert_fit_parity(rp, ref, squares=False)
     finally:
+        bkdist.release_comms()
         dist.destroy_process_group()
 
 
