@@ -1174,6 +1174,203 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup-tiled kernel build: one workgroup per 128 x 128 output tile. The two 128-row panels of X a tile needs
+// are staged ONCE in LDS (k-major, in chunks of 32 columns of X) and shared by the four waves, each of which owns a
+// 64 x 64 quarter (4 x 4 MFMA tiles); per byte written the tile reads 1/4 of what the one-wave-per-32x32 kernel
+// fetches, which is what that kernel loses at large N (X no longer fits the XCDs' L2s: 4.96 TB/s written at
+// N = 20 000, 3.7 at 50 000, 2.9 at 100 000) and at P > 32 (its fragments come straight from global memory).
+// Tile order: XCD-aware (symmetric: the band-major order of the trailing update, SyrkMap; rectangular: xcd_remap).
+// SYM: the lower tiles are computed, an off-diagonal 32 x 32 piece is stored a second time transposed through a
+// wave-private LDS buffer (the panel space, free after the products). Stores are non-temporal 16-byte row pairs:
+// the output is written once and must not displace X from the L2.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KBT_KC = 32;            // columns of X staged per chunk
+constexpr int KBT_LD = 128 + 8;       // panel row stride in doubles (the k rows of a fragment read half the banks apart)
+constexpr size_t kbt_smem_bytes() { return (size_t)(2 * KBT_KC * KBT_LD + 256) * sizeof(double); }
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// kb_store_tile with non-temporal stores
+__device__ __forceinline__ void kbt_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
+                                               int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int lm = lane & 15, lk = lane >> 4;
+  const bool odd = (lane & 1) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + lm;
+        if (vec_ok) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          d2v pr;
+          pr.x = odd ? recv : e[i][j][rp];
+          pr.y = odd ? e[i][j][rp + 1] : recv;
+          const int mrow = m & ~1;                              // first of the row pair
+          const int n = n0 + j * 16 + lk + 4 * (rp + (odd ? 1 : 0));
+          if (n < V) {
+            double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
+            if (mrow + 1 < U) __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(dst));
+            else if (mrow < U) __builtin_nontemporal_store(pr.x, dst);
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int n = n0 + j * 16 + lk + 4 * (rp + rr);
+            if (m < U && n < V) __builtin_nontemporal_store(e[i][j][rp + rr], out + (int64_t)m + (int64_t)n * ldo);
+          }
+        }
+      }
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
+    const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V, int P,
+    const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma, double* __restrict__ out,
+    int64_t ldo, int64_t diag_shift, int tiles_m, int tiles_n, SyrkMap map) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Xa = smem;
+  double* Xb = smem + KBT_KC * KBT_LD;
+  double* sna = smem + 2 * KBT_KC * KBT_LD;
+  double* snb = sna + 128;
+  int tm, tn;
+  if (SYM) {
+    // band-major, one contiguous eighth per XCD (see SyrkMap; 128-wide columns: CPT = 1)
+    const int tiles = map.tiles;
+    const int sq = xcd_remap(blockIdx.x, gridDim.x);
+    int lo = 0, hi = map.nband;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (map.band_start[mid] <= sq) lo = mid; else hi = mid;
+    }
+    int sp = sq - map.band_start[lo];
+    const int r0 = (map.band0 + lo) * map.R, r1 = min(r0 + map.R, tiles);
+    const int cfull = max(min(map.c1, r0 + 1), map.c0);
+    const int nfull = (cfull - map.c0) * (r1 - r0);
+    if (sp < nfull) {
+      tn = map.c0 + sp / (r1 - r0);
+      tm = r0 + sp % (r1 - r0);
+    } else {
+      sp -= nfull;
+      tn = cfull;
+      while (sp >= r1 - tn) { sp -= r1 - tn; ++tn; }
+      tm = tn + sp;
+    }
+  } else {
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    tm = t % tiles_m;
+    tn = t / tiles_m;
+  }
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int lm = lane & 15, lk = lane >> 4;
+  const bool diag_wg = SYM && tm == tn;
+  // a wave whose quarter lies entirely above the diagonal of a diagonal tile has nothing to produce (it still
+  // stages and keeps the barriers)
+  const bool idle = diag_wg && wm < wn;
+  if (tid < 128) sna[tid] = na[min(m0 + tid, U - 1)];
+  else snb[tid - 128] = nb[min(n0 + tid - 128, V - 1)];
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int x = tid & 127, kh = tid >> 7;
+  const double* ap = A + min(m0 + x, U - 1);
+  const double* bp = B + min(n0 + x, V - 1);
+  for (int kc0 = 0; kc0 < P; kc0 += KBT_KC) {
+    const int cnt = min(KBT_KC, P - kc0);
+    const int cnt4 = (cnt + 3) & ~3;
+    double ra[KBT_KC / 2], rb[KBT_KC / 2];
+#pragma unroll
+    for (int q = 0; q < KBT_KC / 2; ++q) {
+      const int k = kh + 2 * q;
+      const int64_t kc = kc0 + min(k, cnt - 1);
+      ra[q] = ap[kc * lda];
+      rb[q] = bp[kc * ldb];
+    }
+    __syncthreads();                       // (the previous chunk's fragment reads are done)
+#pragma unroll
+    for (int q = 0; q < KBT_KC / 2; ++q) {
+      const int k = kh + 2 * q;
+      if (k < cnt4) {
+        Xa[k * KBT_LD + x] = k < cnt ? ra[q] : 0.0;
+        Xb[k * KBT_LD + x] = k < cnt ? rb[q] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (!idle) {
+      for (int kk = 0; kk < cnt4; kk += 4) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = Xa[(kk + lk) * KBT_LD + wm + i * 16 + lm];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = Xb[(kk + lk) * KBT_LD + wn + j * 16 + lm];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                         // the panels are dead: their space becomes the transpose buffers
+  if (idle) return;
+  double* tb = smem + wave * (32 * 33);
+  const bool vec_ok = ((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const int dsh = (int)diag_shift;
+  const bool has_diag = diag_shift >= 0 && (int64_t)m0 < (int64_t)n0 + 128 + diag_shift &&
+                        (int64_t)m0 + 128 > (int64_t)n0 + diag_shift;
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj) {
+      const int pm0 = m0 + wm + 32 * si, pn0 = n0 + wn + 32 * sj;       // this 32 x 32 piece
+      if (diag_wg && pm0 < pn0) continue;                               // above the diagonal
+      double e[2][2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn + 32 * sj + j * 16 + lk + 4 * r;
+          const double nbn = snb[nl];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int ml = wm + 32 * si + i * 16 + lm;
+            double d2 = fma(-2.0, acc[2 * si + i][2 * sj + j][r], sna[ml] + nbn);
+            d2 = fmax(d2, 0.0);
+            double v = exp_nonpos(d2 * neg_inv_sigma);
+            if (has_diag && (m0 + ml) - (n0 + nl) == dsh) v = 1.0;
+            e[i][j][r] = v;
+          }
+        }
+      kbt_store_tile(out, ldo, U, V, pm0, pn0, e, vec_ok);
+      if (SYM && pm0 != pn0) {
+        // E[mloc][nloc] through LDS; the mirrored piece's accumulator layout reads element
+        // (m' = pn0 + 16 i + lm, n' = pm0 + 16 j + lk + 4 r) = E[16 j + lk + 4 r][16 i + lm]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[(i * 16 + lm) * 33 + (j * 16 + lk + 4 * r)] = e[i][j][r];
+        double et[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) et[i][j][r] = tb[(j * 16 + lk + 4 * r) * 33 + (i * 16 + lm)];
+        kbt_store_tile(out, ldo, V, U, pn0, pm0, et, vec_ok);
+      }
+    }
+}
+
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift) {
@@ -1187,7 +1384,52 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   BK_TRY(ws_get(ctx, SLOT_NORMS_B, v * sizeof(double), &pnb));
   BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
   BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
-  if (p <= 128 && A == B && u == v && lda == ldb && diag_shift == 0) {
+  // one workgroup per 128 x 128 tile with the X panels in LDS where the one-wave-per-32x32 kernels lose: large
+  // outputs (X beyond the L2s) and P > 32 (BIGKRLS_KB=wave|tiled forces either; development)
+  static const int kb_force = [] {
+    const char* e = getenv("BIGKRLS_KB");
+    return e ? (std::string(e) == "tiled" ? 1 : (std::string(e) == "wave" ? -1 : 0)) : 0;
+  }();
+  const bool sym = A == B && u == v && lda == ldb && diag_shift == 0;
+  const bool big = u >= 1024 && v >= 1024;
+  if (kb_force > 0 || (kb_force == 0 && big && (p > 32 || (double)u * (double)v >= 32768.0 * 32768.0))) {
+    const int tiles_m = (int)((u + 127) / 128), tiles_n = (int)((v + 127) / 128);
+    SyrkMap mp{};
+    int64_t nt = (int64_t)tiles_m * tiles_n;
+    if (sym) {
+      // rows per band: the A panels of a band are tiny (128 P doubles each): 32 rows keep them and the streamed B
+      // panels far inside the L2
+      static const int r_env = [] { const char* e = getenv("BIGKRLS_KB_R"); return e ? atoi(e) : 0; }();
+      int R = r_env > 0 ? r_env : 32;
+      while ((tiles_m + R - 1) / R > 159) ++R;
+      mp.tiles = tiles_m; mp.c0 = 0; mp.c1 = tiles_m; mp.R = R; mp.band0 = 0; mp.t_off = 0;
+      int64_t acc = 0;
+      int nbands = 0;
+      for (int b0 = 0; b0 * R < tiles_m; ++b0, ++nbands) {
+        mp.band_start[nbands] = (int)acc;
+        for (int tmr = b0 * R; tmr < std::min((b0 + 1) * R, tiles_m); ++tmr) acc += tmr + 1;
+      }
+      mp.band_start[nbands] = (int)acc;
+      mp.nband = nbands;
+      nt = acc;
+    }
+    BK_REQUIRE(nt < (1ll << 31), "kernel_block: too many tiles");
+    BK_TRY(ensure_dyn_smem(ctx, sym ? (const void*)kernel_block_tiled_kernel<true> : (const void*)kernel_block_tiled_kernel<false>,
+                           kbt_smem_bytes()));
+    BK_TRY(prof_begin(ctx, "kernel_block", 2.0 * (double)u * (double)v * (double)p));
+    if (sym)
+      hipLaunchKernelGGL(kernel_block_tiled_kernel<true>, dim3((unsigned)nt), dim3(NT), kbt_smem_bytes(), ctx->stream, A, lda,
+                         (int)u, B, ldb, (int)v, (int)p, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
+                         diag_shift, tiles_m, tiles_n, mp);
+    else
+      hipLaunchKernelGGL(kernel_block_tiled_kernel<false>, dim3((unsigned)nt), dim3(NT), kbt_smem_bytes(), ctx->stream, A, lda,
+                         (int)u, B, ldb, (int)v, (int)p, (const double*)pna, (const double*)pnb, -1.0 / sigma, out, ldo,
+                         diag_shift, tiles_m, tiles_n, mp);
+    BK_CHECK_LAUNCH();
+    BK_TRY(prof_end(ctx, "kernel_block"));
+    return BIGKRLS_OK;
+  }
+  if (p <= 128 && sym) {
     // symmetric Gram matrix (bGaussKernel): lower wave tiles + mirrored stores
     const int tiles = (int)((u + 31) / 32);
     const int64_t ntiles = (int64_t)tiles * (tiles + 1) / 2;
