@@ -96,15 +96,6 @@ SIGNATURES = {
     "bigkrls_dev_multdiag": [vp, vp, i64, i64, i64, vp, vp, i64],
     "bigkrls_dev_eigen": [vp, vp, i64, i64, i64, vp, i64, f64, vp, i64, pi64],
     "bigkrls_dev_eigen_part": [vp, vp, i64, i64, i64, vp, i64, f64, vp, i64, pi64, i32, i32],
-    "bigkrls_dev_s1_open": [vp, i64],
-    "bigkrls_dev_s1_panel": [vp, i64, i64, vp],
-    "bigkrls_dev_s1_av": [vp, i64, i64, vp, i64, i64, vp, i64],
-    "bigkrls_dev_s1_update": [vp, i64, i64, vp, vp, i64, i64, i64],
-    "bigkrls_dev_s1_put": [vp, i64, i64, vp, i64],
-    "bigkrls_dev_s1_panel_begin": [vp, i64, i64, vp],
-    "bigkrls_dev_s1_thin": [vp, i64, i64, vp],
-    "bigkrls_dev_s1_update_cols": [vp, i64, i64, vp, i64, i64, i64],
-    "bigkrls_dev_eigen_resume": [vp, i64, i64, vp, i64, f64, vp, i64, pi64, i32, i32],
     "bigkrls_dev_fill_random": [vp, vp, i64, C.c_uint32],
     "bigkrls_dev_cholqr2": [vp, vp, vp, i64, i64, vp, pi32, vp],
     "bigkrls_dev_lanczos_projected": [vp, vp, vp, i64, i64, vp],

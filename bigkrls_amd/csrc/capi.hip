@@ -439,57 +439,6 @@ int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t
                part_count);
 }
 
-int bigkrls_dev_s1_open(bigkrls_ctx* ctx, int64_t n) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_open(ctx, n);
-}
-
-int bigkrls_dev_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_panel(ctx, n, k, strip);
-}
-
-int bigkrls_dev_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda,
-                      int64_t ncols, double* Yout, int64_t ldy) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_av(ctx, n, k, Acols, lda, ncols, Yout, ldy);
-}
-
-int bigkrls_dev_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda,
-                          int64_t ncols, int64_t row0) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_update(ctx, n, k, Y, Acols, lda, ncols, row0);
-}
-
-int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_put(ctx, n, k, strip, ncols);
-}
-
-int bigkrls_dev_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_panel_begin(ctx, n, k, strip);
-}
-
-int bigkrls_dev_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_thin(ctx, n, k, Y);
-}
-
-int bigkrls_dev_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
-                               int64_t row0) {
-  BK_TRY(check_ctx(ctx));
-  return dist_s1_update_cols(ctx, n, k, Acols, lda, ncols, row0);
-}
-
-int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals, int64_t n_vecs_max,
-                             double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
-                             int32_t part_index, int32_t part_count) {
-  BK_TRY(check_ctx(ctx));
-  return eigen(ctx, nullptr, n, n, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
-               part_count, EIG_RESUME);
-}
-
 int bigkrls_dev_fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed) {
   BK_TRY(check_ctx(ctx));
   return fill_random(ctx, p, count, seed);

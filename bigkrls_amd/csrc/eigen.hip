@@ -2217,6 +2217,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       {
         size_t free_b = 0, total_b = 0;
         BK_HIP(hipMemGetInfo(&free_b, &total_b));
+#ifdef BK_FAULT_INJECT
+        if (const char* fault = getenv("BIGKRLS_FAULT_NOFIT")) {   // (test build) pretend the device is this full
+          if (atoi(fault) != 0) free_b = 0;
+        }
+#endif
         int64_t held = 0;
         for (int sl : {SLOT_EIG_A, SLOT_EIG_Q0, SLOT_EIG_Q1, SLOT_EIG_U}) held += std::min<int64_t>(ctx->ws_bytes[sl], n64 * n64 * 8);
         // the Krylov workspace is released first if that is what it takes

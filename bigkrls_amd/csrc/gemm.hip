@@ -1040,11 +1040,30 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
 // (e[i][j][r] = element (m0 + 16 i + (lane & 15), n0 + 16 j + (lane >> 4) + 4 r)): adjacent lanes
 // (rows 2t, 2t+1) swap one value so that the even lane owns rows (2t, 2t+1) of column n(r) and the
 // odd lane the same rows of column n(r+1).
+template <bool CHECK = true>
 __device__ __forceinline__ void kb_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
                                               int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
   const int lane = threadIdx.x & 63;
   const int lm = lane & 15, lk = lane >> 4;
   const bool odd = (lane & 1) != 0;
+  if (!CHECK) {
+    // interior tile, 16-byte aligned output: no predicates (a predicated store sits in a basic block of its own;
+    // the 32 x 32 kernels spend a fifth of their instructions on the exec-mask bookkeeping of the general path)
+    double* base = out + (int64_t)(m0 + (lm & ~1)) + (int64_t)(n0 + lk + (odd ? 4 : 0)) * ldo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          const double lo = odd ? recv : e[i][j][rp];
+          const double hi = odd ? e[i][j][rp + 1] : recv;
+          *reinterpret_cast<double2*>(base + i * 16 + (int64_t)(j * 16 + 4 * rp) * ldo) = make_double2(lo, hi);
+        }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1152,7 +1171,9 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
         e[i][j][r] = v;
       }
     }
-  kb_store_tile(out, ldo, U, U, m0, n0, e, vec_ok);
+  const bool interior = vec_ok && m0 + 32 <= U && n0 + 32 <= U;     // (wave-uniform)
+  if (interior) kb_store_tile<false>(out, ldo, U, U, m0, n0, e, true);
+  else kb_store_tile<true>(out, ldo, U, U, m0, n0, e, vec_ok);
   if (!diag_tile) {
     // transpose through LDS: E[mloc][nloc], then the mirrored tile's accumulator layout reads
     // element (m' = n0 + 16 i + lm, n' = m0 + 16 j + lk + 4 r) = E[16 j + lk + 4 r][16 i + lm]
@@ -1170,7 +1191,8 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) et[i][j][r] = tb[(j * 16 + lk + 4 * r) * 33 + (i * 16 + lm)];
-    kb_store_tile(out, ldo, U, U, n0, m0, et, vec_ok);
+    if (interior) kb_store_tile<false>(out, ldo, U, U, n0, m0, et, true);
+    else kb_store_tile<true>(out, ldo, U, U, n0, m0, et, vec_ok);
   }
 }
 
@@ -1192,11 +1214,29 @@ constexpr size_t kbt_smem_bytes() { return (size_t)(2 * KBT_KC * KBT_LD + 256) *
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 // kb_store_tile with non-temporal stores
+template <bool CHECK>
 __device__ __forceinline__ void kbt_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
                                                int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
   const int lane = threadIdx.x & 63;
   const int lm = lane & 15, lk = lane >> 4;
   const bool odd = (lane & 1) != 0;
+  if (!CHECK) {
+    double* base = out + (int64_t)(m0 + (lm & ~1)) + (int64_t)(n0 + lk + (odd ? 4 : 0)) * ldo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          d2v pr;
+          pr.x = odd ? recv : e[i][j][rp];
+          pr.y = odd ? e[i][j][rp + 1] : recv;
+          __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(base + i * 16 + (int64_t)(j * 16 + 4 * rp) * ldo));
+        }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1349,7 +1389,9 @@ __global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
             e[i][j][r] = v;
           }
         }
-      kbt_store_tile(out, ldo, U, V, pm0, pn0, e, vec_ok);
+      const bool interior = vec_ok && m0 + 128 <= U && n0 + 128 <= V;    // (workgroup-uniform)
+      if (interior) kbt_store_tile<false>(out, ldo, U, V, pm0, pn0, e, true);
+      else kbt_store_tile<true>(out, ldo, U, V, pm0, pn0, e, vec_ok);
       if (SYM && pm0 != pn0) {
         // E[mloc][nloc] through LDS; the mirrored piece's accumulator layout reads element
         // (m' = pn0 + 16 i + lm, n' = pm0 + 16 j + lk + 4 r) = E[16 j + lk + 4 r][16 i + lm]
@@ -1366,7 +1408,8 @@ __global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) et[i][j][r] = tb[(j * 16 + lk + 4 * r) * 33 + (i * 16 + lm)];
-        kbt_store_tile(out, ldo, V, U, pn0, pm0, et, vec_ok);
+        if (interior) kbt_store_tile<false>(out, ldo, V, U, pn0, pm0, et, true);
+        else kbt_store_tile<true>(out, ldo, V, U, pn0, pm0, et, vec_ok);
       }
     }
 }
@@ -1384,15 +1427,16 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
   BK_TRY(ws_get(ctx, SLOT_NORMS_B, v * sizeof(double), &pnb));
   BK_TRY(row_sqnorms(ctx, A, u, p, lda, (double*)pna));
   BK_TRY(row_sqnorms(ctx, B, v, p, ldb, (double*)pnb));
-  // one workgroup per 128 x 128 tile with the X panels in LDS where the one-wave-per-32x32 kernels lose: large
-  // outputs (X beyond the L2s) and P > 32 (BIGKRLS_KB=wave|tiled forces either; development)
+  // one workgroup per 128 x 128 tile with the X panels in LDS where it beats the one-wave-per-32x32 kernels: P > 32
+  // (measured, TFLOP/s tiled vs wave: N = 100 000, P = 50: 44.7 vs 38.5; N = 30 000, P = 50: 37.2 vs 33.9;
+  //  N = 50 000, P = 20: 21.1 vs 20.7; N = 20 000, P = 20: 17.8 vs 19.9; BIGKRLS_KB=wave|tiled forces either)
   static const int kb_force = [] {
     const char* e = getenv("BIGKRLS_KB");
     return e ? (std::string(e) == "tiled" ? 1 : (std::string(e) == "wave" ? -1 : 0)) : 0;
   }();
   const bool sym = A == B && u == v && lda == ldb && diag_shift == 0;
   const bool big = u >= 1024 && v >= 1024;
-  if (kb_force > 0 || (kb_force == 0 && big && (p > 32 || (double)u * (double)v >= 32768.0 * 32768.0))) {
+  if (kb_force > 0 || (kb_force == 0 && big && p > 32)) {
     const int tiles_m = (int)((u + 127) / 128), tiles_n = (int)((v + 127) / 128);
     SyrkMap mp{};
     int64_t nt = (int64_t)tiles_m * tiles_n;

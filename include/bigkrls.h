@@ -37,7 +37,8 @@
  * device and every wait is bounded: when a watchdog fires (the workgroups were not
  * co-resident, e.g. another process held part of the GPU) the decomposition is
  * redone in the same call with one launch per step -- never a hang, and an error
- * (BIGKRLS_EHIP) only from the distributed stage 1, which cannot be replayed.
+ * (BIGKRLS_EHIP, on every rank) only from the partitioned stage 1 of
+ * bigkrls_fit_dist, which cannot be replayed.
  */
 #ifndef BIGKRLS_H
 #define BIGKRLS_H
@@ -194,51 +195,15 @@ int bigkrls_dev_eigen_part(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t
                            int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
                            int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
 
-/* ---- dense eigensolver with stage 1 partitioned over the GPUs of a node ---------------------------
- * ("Eigen, dense tridiagonalisation"; one process per GPU, the caller owns the
- * collectives -- torch.distributed / RCCL in bigkrls_amd/dist.py). Rank r holds the column block
- * A[:, c0:c1) of the symmetric matrix (column-major, ld n; the block is overwritten), c0 and c1
- * multiples of 64. Per 64-column panel k = 0, 64, ... while k + 64 < n - 1:
- *   1. the owner of columns [k, k+64) broadcasts strip = A[k:n, k:k+64) ((n-k) x 64, ld n-k);
- *   2. every rank: bigkrls_dev_s1_panel (replicated Householder QR of the sub-diagonal panel, T factor);
- *   3. every rank: bigkrls_dev_s1_av on its columns >= k+64: Yout (ncols x 64) = A22[:, own]' V, the rows
- *      of Y = A22 V that belong to them; all-gather -> Y (m x 64, m = n-k-64, contiguous);
- *   4. every rank: bigkrls_dev_s1_update(Y): Z from (V, Y, T) and A22[:, own] -= V Z[own,:]' + Z V[own,:]'
- *      (Acols points at row k+64 of the first own column >= k+64; row0 = that column's index - (k+64)).
- * After the last panel the owners broadcast the remaining columns A[k:n, k:n) and every rank stores them
- * with bigkrls_dev_s1_put. bigkrls_dev_eigen_resume then runs stage 2, the divide & conquer and the
- * back-transform of this rank's slice of the kept eigenvector columns (same contract as
- * bigkrls_dev_eigen_part; the caller all-gathers the column blocks). Between s1_open and eigen_resume
- * no other decomposition may run on the context. n must exceed 256. */
-int bigkrls_dev_s1_open(bigkrls_ctx* ctx, int64_t n);
-int bigkrls_dev_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
-int bigkrls_dev_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda,
-                      int64_t ncols, double* Yout, int64_t ldy);
-int bigkrls_dev_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda,
-                          int64_t ncols, int64_t row0);
-int bigkrls_dev_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
-/* Look-ahead form of the same step. bigkrls_dev_s1_update = bigkrls_dev_s1_thin (the thin products of panel k from
- * the gathered Y) + bigkrls_dev_s1_update_cols (the update of `ncols` own columns starting at row `row0` of the
- * trailing matrix). A rank calls s1_thin, updates the NEXT panel's columns first if it owns them, takes part in the
- * broadcast of the next strip, starts the next panel's factorisation with bigkrls_dev_s1_panel_begin -- it runs on
- * the context's look-ahead stream after everything queued so far and returns at once -- and then updates its
- * remaining columns beside it; the next s1_av / s1_thin / s1_put waits for the factorisation. */
-int bigkrls_dev_s1_panel_begin(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
-int bigkrls_dev_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y);
-int bigkrls_dev_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
-                               int64_t row0);
-int bigkrls_dev_eigen_resume(bigkrls_ctx* ctx, int64_t n, int64_t n_vals, double* vals,
-                             int64_t n_vecs_max, double h_keep_thresh, double* vecs, int64_t ldv,
-                             int64_t* h_n_vecs, int32_t part_index, int32_t part_count);
 /* p[0 .. count) (device) = uniform values in [-0.5, 0.5) that depend on the element index and the seed only: the
  * start block of the block Lanczos, the same on every rank (seed 20240229 is the single-GPU library's). */
 int bigkrls_dev_fill_random(bigkrls_ctx* ctx, double* p, int64_t count, uint32_t seed);
 /* Orthonormalise the columns of the n x b block W (device, column-major, ld n; b <= 128) by Cholesky-QR applied
  * twice, in place; tmp: device scratch of the same size. h_R (host, b x b column-major) receives the upper
  * triangular R with W_in = W_out R, *h_breakdown is 1 when the Gram matrix was not positive definite (W is then
- * undefined); d_R (device, b x b, may be NULL) receives the same R. The block Lanczos step of the row-block path
- * (bigkrls_amd/dist.py) calls it on the replicated block; the reference has no counterpart (its Neig < N branch is
- * arma::eigs_sym, src/eigen.cpp:18-22). */
+ * undefined); d_R (device, b x b, may be NULL) receives the same R. One step of the library's block Lanczos
+ * (exposed for tests; the reference has no counterpart: its Neig < N branch is arma::eigs_sym,
+ * src/eigen.cpp:18-22). */
 int bigkrls_dev_cholqr2(bigkrls_ctx* ctx, double* W, double* tmp, int64_t n, int64_t b, double* h_R,
                         int32_t* h_breakdown, double* d_R);
 /* d_T (device, m x m column-major, m = steps b) = the block-tridiagonal projected matrix of a block Lanczos run:

@@ -45,6 +45,17 @@ n2 = 16384                                                   # the size at which
 X2, _ = synth(n2, p, 10)
 K2 = ops.bGaussKernel(ctx.from_numpy((X2 - X2.mean(0)) / X2.std(0, ddof=1)), float(p))
 fb = ops.bEigen(K2, 64, -1.0)
+# ... and when the dense workspace (4 n^2 doubles) does not fit, the non-convergence is reported as such, with what the
+# iteration saw at its checks, instead of an out-of-memory error from inside the dense path
+os.environ["BIGKRLS_FAULT_NOFIT"] = "1"
+ctx.release_workspace()          # (the workspace the dense fallback just grew counts as held otherwise)
+try:
+    ops.bEigen(K2, 64, -1.0)
+    raise AssertionError("a block Lanczos that does not converge must not succeed when the dense path does not fit")
+except L.BigKRLSError as e:
+    assert e.code == L.ENOCONV, e
+    assert "dense fallback does not fit" in str(e) and "check steps=" in str(e), str(e)
+del os.environ["BIGKRLS_FAULT_NOFIT"]
 del os.environ["BIGKRLS_FAULT"]
 kr = ops.bEigen(K2, 64, -1.0)
 assert rel(fb.values, kr.values) < 1e-10
