@@ -110,6 +110,17 @@ int download(bigkrls_ctx* ctx, double* dst_host, const double* src_dev, int64_t 
   return BIGKRLS_OK;
 }
 
+// out (n x (r1 - r0), ld n) = alpha M Q[r0:r1, :]' with M = Q diag(w): the rows r0:r1 of the block are symmetric
+// (lower tiles computed and mirrored, half the MFMA work), the rows above and below plain products
+int vcov_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, int64_t r0, int64_t r1, double alpha, const double* M,
+              const double* Q, double* out) {
+  const int64_t nloc = r1 - r0;
+  if (r0 > 0) BK_TRY(gemm(ctx, 0, 1, r0, nloc, k, alpha, M, n, Q + r0, n, 0.0, out, n));
+  BK_TRY(syrk_mirror_set(ctx, nloc, k, alpha, M + r0, n, Q + r0, n, out + r0, n));
+  if (r1 < n) BK_TRY(gemm(ctx, 0, 1, n - r1, nloc, k, alpha, M + r1, n, Q + r0, n, 0.0, out + r1, n));
+  return BIGKRLS_OK;
+}
+
 }  // namespace
 }  // namespace bk
 
@@ -376,7 +387,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
           BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_c, n));
           if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
         } else if (nloc > 0) {   // the column block V[:, r0:r1) = (Q diag(w)) Q[r0:r1, :]': kept sharded, no exchange
-          BK_TRY(gemm(ctx, 0, 1, n, nloc, k, sd2, dM, n, dQ + r0, n, 0.0, out->d_vcov_c, n));
+          BK_TRY(vcov_cols(ctx, n, k, r0, r1, sd2, dM, dQ, out->d_vcov_c));
         }
         BK_HIP(hipStreamSynchronize(st));
       }
@@ -392,7 +403,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
           BK_TRY(syrk_mirror_set(ctx, n, k, sd2, dM, n, dQ, n, out->d_vcov_fitted, n));
           if (ctx->profile) BK_TRY(prof_end(ctx, "vcov_syrk"));
         } else if (nloc > 0) {
-          BK_TRY(gemm(ctx, 0, 1, n, nloc, k, sd2, dM, n, dQ + r0, n, 0.0, out->d_vcov_fitted, n));
+          BK_TRY(vcov_cols(ctx, n, k, r0, r1, sd2, dM, dQ, out->d_vcov_fitted));
         }
         BK_HIP(hipStreamSynchronize(st));
       }

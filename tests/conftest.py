@@ -17,6 +17,8 @@ WORLD_CASES = {
     "dense_world2": ["3000", "8", "2"],
     "dense_world3_ragged": ["2500", "6", "3"],
     "krylov_world2": ["17000", "10", "2", "--krylov", "60"],
+    "dense_world4_empty_rank": ["300", "4", "4", "--eigtrunc", "0.001"],          # blocks of 128 columns: the fourth rank owns nothing
+    "replicated_world2": ["200", "3", "2", "--eigtrunc", "0.001"],                # n <= 256: K gathered, Q by all-reduce
 }
 _world_runs = {}
 

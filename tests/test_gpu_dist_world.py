@@ -1,8 +1,9 @@
-"""WORLD_SIZE 2 and 3 through the HIP backend of the row-block path on one GPU (tests/_dist_world_gpu.py): the
-partitioned dense stage 1 with column-block offsets (also a ragged last block), the split back-transform and the
-sharded block Lanczos, every rank compared with the single-process fit of the same data. The rank processes are
-started by conftest.py at session start; RCCL itself is covered at world size 1 (test_gpu_fit.py) because it refuses
-two ranks on one device."""
+"""bigkrls_fit_dist at WORLD_SIZE 2, 3 and 4 on one GPU through the callback communicator
+(tests/_dist_world_gpu.py): the partitioned dense stage 1 with column-block offsets (a ragged last block, a rank
+that owns nothing), the split back-transform, the sharded block Lanczos, the replicated decomposition of a tiny
+problem, the row-block lambda search; every rank compared with the single-process fit of the same data. The rank
+processes are started by conftest.py at session start; RCCL itself is covered at world size 1 (test_gpu_fit.py)
+because it refuses two ranks on one device."""
 import pytest
 
 from conftest import WORLD_CASES
