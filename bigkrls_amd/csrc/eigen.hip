@@ -1938,11 +1938,14 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   void* pY = nullptr;
   bool converged = false;
   // each check is a dense eigensolve of T (latency-bound, ~12 us per row of T); the first one comes at a
-  // subspace of 4k columns, or of 2k where a step costs more than such a check (sizes only: the schedule, and
+  // subspace of 5k columns, or of 2.5k where a step costs more than such a check (sizes only: the schedule, and
   // with it the result, must not depend on timing)
   const double step_s_est = 2.0 * (double)n * (double)n * b / 50e12;
   const bool check_is_cheap = 12e-6 * 4.0 * (double)k < step_s_est;
-  int next_check = (int)std::max<int64_t>(2, ((check_is_cheap ? 2 : 4) * k + b - 1) / b);
+  // (C4: the pairs converge at step 27, C5 at step 23; a first check at 4k / 2k columns -- step 16 in both -- sits on the
+  //  plateau of the worst residual and only costs a dense eigensolve of T: 5k / 2.5k columns, step 20, leaves three
+  //  checks at C4 (20, 25, 27) and two at C5 (20, 23) instead of four and three)
+  int next_check = (int)std::max<int64_t>(2, ((check_is_cheap ? 5 : 10) * k / 2 + b - 1) / b);
   if (const char* fc = getenv("BIGKRLS_KRY_FIRST_CHECK")) next_check = std::max(2, atoi(fc));   // (development)
   while (true) {
     // ---- one block Lanczos step: W = K B_j, orthogonalised against every block so far (CGS2) ---
