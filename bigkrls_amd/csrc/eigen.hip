@@ -1897,6 +1897,10 @@ static int kry_agree_min(const KTimes& op, double* vals, int count) {
   return comm_all_reduce_host(op.comm, vals, count, COMM_MIN);
 }
 
+// a local status that every rank must share before the next collective (allocations: the one local failure that can
+// realistically differ between ranks); single GPU: the status itself
+static int kry_agree_status(const KTimes& op, int rc) { return op.comm ? comm_agree(op.comm, rc) : rc; }
+
 static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t k, double* vals,
                         int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv,
                         int64_t* h_n_vecs, int part_index, int part_count) {
@@ -1906,11 +1910,17 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   kry_diag.clear();
   const int64_t maxdim = std::min<int64_t>(n / 2 / b * b, std::max<int64_t>(16 * k, 4096) / b * b);
   const int maxsteps = (int)(maxdim / b);
-  void *pB = nullptr, *pW = nullptr, *pC = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_KRY_B, n * maxdim * sizeof(double), &pB));
-  BK_TRY(ws_get(ctx, SLOT_KRY_W, 2 * n * (int64_t)std::max<int64_t>(b, k) * sizeof(double), &pW));
-  BK_TRY(ws_get(ctx, SLOT_KRY_C, (maxdim * b + 5 * b * b + 8 + k * k + 2 * k + 2 * (int64_t)maxsteps * b * b) *
-                                     sizeof(double), &pC));
+  void *pB = nullptr, *pW = nullptr, *pC = nullptr, *pC2 = nullptr;
+  {
+    int rc = ws_get(ctx, SLOT_KRY_B, n * maxdim * sizeof(double), &pB);
+    if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_W, 2 * n * (int64_t)std::max<int64_t>(b, k) * sizeof(double), &pW);
+    if (rc == BIGKRLS_OK)
+      rc = ws_get(ctx, SLOT_KRY_C, (maxdim * b + 5 * b * b + 8 + k * k + 2 * k + 2 * (int64_t)maxsteps * b * b) *
+                                       sizeof(double), &pC);
+    if (rc == BIGKRLS_OK && kop.comm)   // the staging of the per-step all-gather, before the first one is entered
+      rc = ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(kop.comm->nranks + 1) * kop.nb * std::max<int64_t>(b, k) * sizeof(double), &pC2);
+    BK_TRY(kry_agree_status(kop, rc));
+  }
   double* B = (double*)pB;
   double* W = (double*)pW;
   double* W2 = W + n * std::max<int64_t>(b, k);
@@ -1974,8 +1984,11 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     if (last || steps >= next_check) {
       const int64_t m = (int64_t)steps * b;
       void *pT = nullptr;
-      BK_TRY(ws_get(ctx, SLOT_KRY_T, (m * m + m) * sizeof(double), &pT));
-      BK_TRY(ws_get(ctx, SLOT_KRY_Y, m * k * sizeof(double), &pY));
+      {
+        int rc = ws_get(ctx, SLOT_KRY_T, (m * m + m) * sizeof(double), &pT);
+        if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_Y, m * k * sizeof(double), &pY);
+        BK_TRY(kry_agree_status(kop, rc));
+      }
       double* dT = (double*)pT;
       double* dvalsT = dT + m * m;
       hipLaunchKernelGGL(kry_assemble_t, dim3((unsigned)std::min<int64_t>((m * m + 255) / 256, 8192)), dim3(256), 0, st,
@@ -2535,6 +2548,14 @@ static int dist_state(bigkrls_ctx* ctx, int64_t n, DistS1** out) {
 }
 
 int dist_s1_open(bigkrls_ctx* ctx, int64_t n) {
+#ifdef BK_FAULT_INJECT
+  // BIGKRLS_FAULT=s1_open (test build, set in ONE rank's process): a local failure that the other ranks must learn of
+  if (const char* f = getenv("BIGKRLS_FAULT"))
+    if (std::string(f) == "s1_open") {
+      set_error("injected fault: the stage-1 workspace of this rank could not be allocated");
+      return BIGKRLS_ENOMEM;
+    }
+#endif
   return eigen(ctx, nullptr, n, n, n, nullptr, 0, -1.0, nullptr, n, nullptr, 0, 1, EIG_SETUP_ONLY);
 }
 

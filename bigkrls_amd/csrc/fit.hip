@@ -224,9 +224,25 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
 
   // ---- workspace ---------------------------------------------------------------------------------
   const int64_t small_doubles = n * p + n * (3 + 5 * std::max<int64_t>(pd, 1)) + 3 * neig + 64;
-  void *psmall = nullptr, *pq = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_FIT_SMALL, small_doubles * (int64_t)sizeof(double), &psmall));
-  BK_TRY(ws_get(ctx, SLOT_FIT_Q, n * neig * (int64_t)sizeof(double), &pq));
+  // A local failure (an allocation, a launch) must not let this rank leave while its peers wait in the next
+  // collective: the status of every local stretch is agreed (all-reduce MIN) before the exchange that follows it.
+  auto agreed = [&](int rc) { return comm ? comm_agree(comm, rc) : rc; };
+  void *psmall = nullptr, *pq = nullptr, *pk = nullptr, *pm_pre = nullptr;
+  double* pin = nullptr;
+  const int64_t pin_doubles = std::max<int64_t>(n * std::max<int64_t>(p, pd) + n, 2 * neig + 64);
+  auto allocate = [&]() -> int {
+    BK_TRY(ws_get(ctx, SLOT_FIT_SMALL, small_doubles * (int64_t)sizeof(double), &psmall));
+    BK_TRY(ws_get(ctx, SLOT_FIT_Q, n * neig * (int64_t)sizeof(double), &pq));
+    if (!out->d_K)   // K: the whole matrix, or this rank's column block K[:, r0:r1) (n x nloc, ld n)
+      BK_TRY(ws_get(ctx, comm ? SLOT_DIST_K : SLOT_FIT_K, n * std::max<int64_t>(nloc, 1) * (int64_t)sizeof(double), &pk));
+    if (comm && vcov_est && (out->d_vcov_c || out->d_vcov_fitted))   // Q diag(w) of the variance matrices, up front
+      BK_TRY(ws_get(ctx, SLOT_FIT_M, n * neig * (int64_t)sizeof(double), &pm_pre));
+    if (comm)      // the staging of the row-block all-gathers (c, yhat, D, S)
+      BK_TRY(ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(comm->nranks + 1) * nb * std::max<int64_t>(pd, 1) * (int64_t)sizeof(double), &pm_pre));
+    BK_TRY(pinned_get(ctx, pin_doubles, &pin));
+    return BIGKRLS_OK;
+  };
+  BK_TRY(agreed(allocate()));
   double* q = (double*)psmall;
   double* dX = q; q += n * p;
   double* dy = q; q += n;
@@ -241,16 +257,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   double* da = q; q += neig;
   double* dw = q; q += neig;
   double* dQ = (double*)pq;
-  // K: the whole matrix, or this rank's column block K[:, r0:r1) (n x nloc, ld n)
-  double* dK = out->d_K;
-  if (!dK) {
-    void* pk = nullptr;
-    BK_TRY(ws_get(ctx, comm ? SLOT_DIST_K : SLOT_FIT_K, n * std::max<int64_t>(nloc, 1) * (int64_t)sizeof(double), &pk));
-    dK = (double*)pk;
-  }
-  double* pin = nullptr;
-  const int64_t pin_doubles = std::max<int64_t>(n * std::max<int64_t>(p, pd) + n, 2 * neig + 64);
-  BK_TRY(pinned_get(ctx, pin_doubles, &pin));
+  double* dK = out->d_K ? out->d_K : (double*)pk;
 
   PhaseTimer timer(ctx);
   timer.mark();
@@ -270,7 +277,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
 
   // ---- step 1: kernel (:262) ----------------------------------------------------------------------
   if (!comm) BK_TRY(kernel_block(ctx, dX, n, n, dX, n, n, p, sigma, dK, n, 0));
-  else if (nloc > 0) BK_TRY(kernel_block(ctx, dX, n, n, dX + r0, nloc, n, p, sigma, dK, n, r0));   // K[:, r0:r1): no exchange
+  else BK_TRY(agreed(nloc > 0 ? kernel_block(ctx, dX, n, n, dX + r0, nloc, n, p, sigma, dK, n, r0) : BIGKRLS_OK));   // K[:, r0:r1): no exchange
   timer.mark();                                                           // kernel
 
   // ---- step 2: eigen (:266-269; bEigen's lastkeeper rule on the device side) ------------------------
@@ -322,8 +329,12 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     BK_TRY(qty(ctx, dQ, n, k, n, dy, da));
   } else {
     // a = Q'y from the row blocks: one all-reduce of K doubles
-    if (nloc > 0) BK_TRY(qty(ctx, dQ + r0, nloc, k, n, dy + r0, da));
-    else BK_HIP(hipMemsetAsync(da, 0, (size_t)k * sizeof(double), st));
+    auto own_qty = [&]() -> int {
+      if (nloc > 0) return qty(ctx, dQ + r0, nloc, k, n, dy + r0, da);
+      BK_HIP(hipMemsetAsync(da, 0, (size_t)k * sizeof(double), st));
+      return BIGKRLS_OK;
+    };
+    BK_TRY(agreed(own_qty()));
     BK_TRY(comm_all_reduce(comm, da, k, COMM_SUM));
   }
   double lambda = opt->lambda;
@@ -349,10 +360,10 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
   } else {
     // own rows of c and of K c (K symmetric: K[:, r0:r1)' c), one all-gather each; Le is a sum over the row blocks
-    if (nloc > 0) BK_TRY(solveforc(ctx, dQ + r0, nloc, k, n, dvals, da, lambda, dDloc, &Le));
+    BK_TRY(agreed(nloc > 0 ? solveforc(ctx, dQ + r0, nloc, k, n, dvals, da, lambda, dDloc, &Le) : BIGKRLS_OK));
     BK_TRY(comm_all_reduce_host(comm, &Le, 1, COMM_SUM));
     BK_TRY(comm_gather_rows(comm, dDloc, nloc, std::max<int64_t>(nloc, 1), 1, nb, n, dc, n));
-    if (nloc > 0) BK_TRY(gemv(ctx, 1, n, nloc, 1.0, dK, n, dc, 0.0, dSloc));
+    BK_TRY(agreed(nloc > 0 ? gemv(ctx, 1, n, nloc, 1.0, dK, n, dc, 0.0, dSloc) : BIGKRLS_OK));
     BK_TRY(comm_gather_rows(comm, dSloc, nloc, std::max<int64_t>(nloc, 1), 1, nb, n, dyhat, n));
   }
   std::vector<double> coeffs(n), yhat(n);
@@ -442,7 +453,8 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     } else {
       // own rows of D and S from the own column block, one all-gather of each (N x P')
       const int64_t ldl = std::max<int64_t>(nloc, 1);
-      if (nloc > 0) BK_TRY(deriv_rows(ctx, dK, n, nloc, n, r0, dXe, pd, n, isbin.data(), dc, sigma, dDloc, ldl, dSloc, ldl));
+      BK_TRY(agreed(nloc > 0 ? deriv_rows(ctx, dK, n, nloc, n, r0, dXe, pd, n, isbin.data(), dc, sigma, dDloc, ldl, dSloc, ldl)
+                             : BIGKRLS_OK));
       BK_TRY(comm_gather_rows(comm, dDloc, nloc, ldl, pd, nb, n, dD, n));
       BK_TRY(comm_gather_rows(comm, dSloc, nloc, ldl, pd, nb, n, dS, n));
     }

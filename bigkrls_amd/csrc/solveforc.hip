@@ -455,7 +455,10 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64
   const int64_t st_d = (2 * (int64_t)sizeof(SfState) + 7) / 8;
   const int64_t nd = st_d + 2 * rb + 2 * DEV_TRACE + (splits > 1 ? 2 * (int64_t)splits * n : 0) + 16;
   void* p = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_SOLVE_PART, nd * sizeof(double), &p));
+  {
+    const int rc = ws_get(ctx, SLOT_SOLVE_PART, nd * sizeof(double), &p);
+    BK_TRY(comm ? comm_agree(comm, rc) : rc);     // (before the first all-reduce of the chain)
+  }
   SfState* dstate = (SfState*)p;
   double* le = (double*)p + st_d;
   double* dtrace = le + 2 * rb;

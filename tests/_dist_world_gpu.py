@@ -21,7 +21,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 def launcher():
     args = [a for a in sys.argv[1:]]
-    pos = [a for a in args if not a.startswith("--") and a.isdigit()][:3]
+    pos = [a for a in args if a.isdigit()][:3]
     world = int(pos[2]) if len(pos) > 2 else 2
     port = str(29600 + os.getpid() % 200)
     procs = []
@@ -55,6 +55,13 @@ def worker():
     #  quirk Q7; the small cases pass a threshold)
     trunc = float(sys.argv[sys.argv.index("--eigtrunc") + 1]) if "--eigtrunc" in sys.argv else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    fault_rank = int(sys.argv[sys.argv.index("--fault-rank") + 1]) if "--fault-rank" in sys.argv else None
+    if fault_rank is not None:
+        # the test build of the library (fault-injection hooks compiled in); the fault itself only in ONE rank's process
+        import bigkrls_amd._lib as L
+        L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "libbigkrls_hip_fault.so")
+        if rank == fault_rank:
+            os.environ["BIGKRLS_FAULT"] = "s1_open"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = bk.Context(0)
     comm = bkdist.get_comm(ctx, "host")                   # bigkrls_comm_create_callbacks: collectives staged through gloo
@@ -63,6 +70,21 @@ def worker():
     kw = dict(Neig=neig) if neig else {}
     if trunc is not None:
         kw["eigtrunc"] = trunc
+    if fault_rank is not None:
+        # a rank that fails locally must not leave its peers waiting in a collective: EVERY rank gets the error
+        from bigkrls_amd._lib import BigKRLSError, ENOMEM
+        try:
+            bkdist.bigKRLS_dist(y, X, comm=comm, **kw)
+            ok = False
+            msg = "no error raised"
+        except BigKRLSError as e:
+            msg = str(e)
+            ok = e.code == ENOMEM and (("injected fault" in msg) if rank == fault_rank else ("another rank" in msg))
+        print(f"rank {rank}/{world} fault injected in rank {fault_rank}: {msg[:120]}" + (" OK" if ok else " MISMATCH"), flush=True)
+        dist.barrier()
+        bkdist.release_comms()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     T = {}
     t0 = time.perf_counter()
     out = bkdist.bigKRLS_dist(y, X, comm=comm, timings=T, keep_outputs=True, **kw)

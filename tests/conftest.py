@@ -18,7 +18,9 @@ WORLD_CASES = {
     "dense_world3_ragged": ["2500", "6", "3"],
     "krylov_world2": ["17000", "10", "2", "--krylov", "60"],
     "dense_world4_empty_rank": ["300", "4", "4", "--eigtrunc", "0.001"],          # blocks of 128 columns: the fourth rank owns nothing
-    "replicated_world2": ["200", "3", "2", "--eigtrunc", "0.001"],                # n <= 256: K gathered, Q by all-reduce
+    "replicated_world2": ["200", "3", "2", "--eigtrunc", "0.001"],
+    # a local failure in ONE rank (test build of the library): every rank must return the error, none may hang
+    "dense_world2_rank_failure": ["600", "4", "2", "--eigtrunc", "0.001", "--fault-rank", "1"],                # n <= 256: K gathered, Q by all-reduce
 }
 _world_runs = {}
 
