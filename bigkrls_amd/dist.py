@@ -180,6 +180,12 @@ def release_comms() -> None:
     _COMMS.clear()
 
 
+# a communicator must go before the context it points at: at interpreter exit, before the module globals are torn down
+import atexit  # noqa: E402
+
+atexit.register(release_comms)
+
+
 def bigKRLS_dist(y, X, sigma=None, derivative=True, which_derivatives=None, Neig=None, eigtrunc=None,
                  lambda_=None, L=None, U=None, ctx: Optional[Context] = None, comm: Optional[Comm] = None,
                  timings: Optional[Dict[str, float]] = None, trace=None, keep_outputs=True,
