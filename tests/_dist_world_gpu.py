@@ -70,6 +70,11 @@ def worker():
     kw = dict(Neig=neig) if neig else {}
     if trunc is not None:
         kw["eigtrunc"] = trunc
+    if "--options" in sys.argv:
+        # a binary last column (first differences, src/bigderiv_v3.cpp:31-87), a which.derivatives subset that
+        # includes it (quirk Q6 in the rescaling) -- the row-block derivative pass with its all-gathers
+        X[:, -1] = (X[:, -1] > 0.12345).astype(float)
+        kw["which_derivatives"] = [2, p]
     if fault_rank is not None:
         # a rank that fails locally must not leave its peers waiting in a collective: EVERY rank gets the error
         from bigkrls_amd._lib import BigKRLSError, ENOMEM
@@ -101,6 +106,7 @@ def worker():
         "coeffs": rel(out["coeffs"], one["coeffs"]),
         "yfitted": rel(out["yfitted"], one["yfitted"]),
         "avgderivatives": rel(out["avgderivatives"], one["avgderivatives"]),
+        "derivatives": rel(out["derivatives"], one["derivatives"]),
         "var.avgderivatives": rel(out["var.avgderivatives"], one["var.avgderivatives"]),
         "K.eigenvalues[:lastkeeper]": rel(np.asarray(out["K.eigenvalues"])[: out["lastkeeper"]],
                                           np.asarray(one["K.eigenvalues"])[: one["lastkeeper"]]),

@@ -19,6 +19,7 @@ WORLD_CASES = {
     "krylov_world2": ["17000", "10", "2", "--krylov", "60"],
     "dense_world4_empty_rank": ["300", "4", "4", "--eigtrunc", "0.001"],          # blocks of 128 columns: the fourth rank owns nothing
     "replicated_world2": ["200", "3", "2", "--eigtrunc", "0.001"],
+    "dense_world3_binary_which": ["1200", "5", "3", "--eigtrunc", "0.01", "--options"],
     # a local failure in ONE rank (test build of the library): every rank must return the error, none may hang
     "dense_world2_rank_failure": ["600", "4", "2", "--eigtrunc", "0.001", "--fault-rank", "1"],                # n <= 256: K gathered, Q by all-reduce
 }
