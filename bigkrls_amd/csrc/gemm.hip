@@ -54,7 +54,7 @@ constexpr int lds_stage(int w) {   // room for either layout
   return BK * (w + GEMM_KX_PAD) > w * LDS_XK ? BK * (w + GEMM_KX_PAD) : w * LDS_XK;
 }
 // one layout only: the 128 x 64 tile of the trailing update (both operands x-contiguous) needs 52 KB with this and
-// 54 KB with lds_stage() -- three workgroups fit the 160 KB of a CU only with the former
+// 54 KB with lds_stage() -- three workgroups fit the 160 KB of a CU only with the former (see syrk_mirror_kernel)
 constexpr int lds_stage_of(bool contig_x, int w) { return contig_x ? BK * (w + GEMM_KX_PAD) : w * LDS_XK; }
 template <bool CONTIG_X, int W>
 __device__ __forceinline__ int lds_at(int k, int x) {
@@ -354,8 +354,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // ---------------------------------------------------------------------------
 // plain GEMM kernels
 // ---------------------------------------------------------------------------
+// workgroups per CU of gemm_kernel<TA, TB, BN>: the N,N kernel with 64-wide tiles (A22 V of stage 1, K B_j of the
+// block Lanczos) fits three with the layout-exact LDS stages when it gives up the second k-tile in flight
+#ifndef GEMM_NN64_OCC
+#define GEMM_NN64_OCC 2
+#endif
 template <bool TA, bool TB, int BN>
-__global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, double alpha, double beta,
+constexpr int gemm_occ() { return (!TA && !TB && BN == 64) ? GEMM_NN64_OCC : GEMM_OCC; }
+template <bool TA, bool TB, int BN>
+constexpr size_t gemm_smem_bytes() {
+  return gemm_occ<TA, TB, BN>() > GEMM_OCC
+             ? (size_t)(2 * lds_stage_of(!TA, BM) + 2 * lds_stage_of(TB, BN)) * sizeof(double)
+             : smem_bytes(BN);
+}
+template <bool TA, bool TB, int BN>
+__global__ __launch_bounds__(NT, (gemm_occ<TA, TB, BN>())) void gemm_kernel(GemmOperands g, double alpha, double beta,
                                                   double* __restrict__ C, int64_t ldc,
                                                   int tiles_m, int tiles_n, int k_chunk,
                                                   double* __restrict__ partial) {
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(NT, GEMM_OCC) void gemm_kernel(GemmOperands g, doub
   const int kbeg = z * k_chunk;
   const int kend = min(g.K, kbeg + k_chunk);
   d4 acc[4][BN / 32];
-  gemm_tile<TA, TB, BN, false, (BN <= GEMM_DEEP_BN)>(g, m0, n0, kbeg, kend, smem, acc);
+  gemm_tile<TA, TB, BN, false, (BN <= GEMM_DEEP_BN && gemm_occ<TA, TB, BN>() <= GEMM_OCC)>(g, m0, n0, kbeg, kend, smem, acc);
   if (partial != nullptr) {
     double* P = partial + (int64_t)z * g.M * g.N;
     const int M = g.M, N = g.N;
@@ -461,8 +474,9 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
     // slab is written and read again (16 bytes per output element at ~5 TB/s) plus a fixed ~0.2 us
     const double per_split = 3.2e-6 * (double)g.M * (double)g.N + 0.2;
     double best = 1e30;
+    constexpr int resident = 256 * gemm_occ<TA, TB, BN>();
     for (int sp = 1; sp <= maxs; ++sp) {
-      const int rounds = (ntile * sp + 511) / 512;
+      const int rounds = (ntile * sp + resident - 1) / resident;
       const double cost = 0.06 * rounds * ((double)g.K / sp) + per_split * sp;
       if (cost < best - 1e-9) { best = cost; splits = sp; }
     }
@@ -480,9 +494,10 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
     partial = (double*)p;
   }
   auto kern = gemm_kernel<TA, TB, BN>;
-  BK_TRY(ensure_dyn_smem(ctx, (const void*)kern, smem_bytes(BN)));
+  constexpr size_t smem = gemm_smem_bytes<TA, TB, BN>();
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)kern, smem));
   dim3 grid(ntile, splits);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), smem_bytes(BN), ctx->stream, g, alpha, beta, C, ldc,
+  hipLaunchKernelGGL(kern, grid, dim3(NT), smem, ctx->stream, g, alpha, beta, C, ldc,
                      tiles_m, tiles_n, k_chunk, partial);
   BK_CHECK_LAUNCH();
   if (splits > 1) {
@@ -600,13 +615,24 @@ struct SyrkMap {
   int band_start[160];  // band b (relative) starts at sequence index band_start[b]; [nband] = number of tiles
 };
 
+#ifndef SYRK64_OCC
+#define SYRK64_OCC 3
+#endif
+#ifndef SYRK64_DEEP
+#define SYRK64_DEEP 0
+#endif
+#ifndef SYRK64_LDS_EXACT
+#define SYRK64_LDS_EXACT 0
+#endif
 template <int BN, bool ACCUM = true>
-__global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_kernel(
+__global__ __launch_bounds__(NT, (BN == 64 ? SYRK64_OCC : GEMM_OCC)) void syrk_mirror_kernel(
     GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, SyrkMap map) {
-  // Tiles are 128 x BN. BN = 64 halves the accumulators so that THREE workgroups fit a CU: the
-  // MFMA loop (8 k-tiles at k = 128) and the read-modify-write epilogue of one workgroup are
-  // both latency-bound, and with identical tiles two co-resident workgroups run them in
-  // lockstep; a third keeps the MFMA pipe and the memory system busy at the same time.
+  // Tiles are 128 x BN. BN = 64 halves the accumulators; its 154 VGPRs would let THREE workgroups share a CU, and with
+  // the layout-exact 52 KB of LDS (SYRK64_LDS_EXACT) they do: 5-7% faster in isolation (m = 20 000: k = 128 1 817 ->
+  // 1 693 us, k = 256 2 404 -> 2 286). The fit keeps the 54 KB request (lds_stage(), room for either layout), i.e. TWO
+  // per CU: the panel QR of the next panel runs beside this kernel, its workgroups need 105 KB of LDS and 256 VGPRs,
+  // and with three of these per CU a finished one leaves a hole they do not fit into -- the QR then starts late on
+  // the critical path (C3 fit 0.469 -> 0.511 s; profiles/r03/r03m_*).
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NJ = BN / 32;
   constexpr int CPT = 128 / BN;   // tile columns per 128-wide column pair
@@ -649,7 +675,7 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   const int m0 = tm * BM, n0 = tc * BN;
   d4 acc[4][NJ];
   BK_TRACE_STAMP(0)
-  gemm_tile<false, true, BN>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
+  gemm_tile<false, true, BN, false, (BN == 64 && SYRK64_DEEP)>(g, m0, n0, 0, g.K, smem, acc);  // ends with a block barrier
   BK_TRACE_STAMP(1)
   const int M = g.M;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -742,243 +768,6 @@ __global__ __launch_bounds__(NT, (BN == 64 ? 3 : GEMM_OCC)) void syrk_mirror_ker
   BK_TRACE_STAMP(2)
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised, persistent form of the mirrored rank-k update (128 x 64 tiles). One workgroup of 512 threads per
-// CU walks its share of the tile sequence (SyrkMap order, one contiguous eighth per XCD):
-//   waves 0-3 ("compute"): the k-loop of tile i -- operands global -> registers -> LDS (two stages), MFMA -- and,
-//                          without draining the pipeline, the first operand tile of tile i + 1;
-//   waves 4-7 ("epilogue"): the read-modify-write of tile i - 1 from an LDS copy of its accumulators: C += alpha R
-//                          on the lower part (first half of the k-tiles), the mirrored stores (second half),
-//                          one chunk per k-tile of the compute waves, separated by the same workgroup barriers.
-// The kernel with one role per wave measured T = T_MFMA + (0.2 ... 0.6) T_memory (no tile's epilogue overlaps its own
-// MFMA loop, and co-resident workgroups drift into phase); here the two run on different waves of the same CU by
-// construction, and the operand pipeline is filled once per workgroup instead of once per tile.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int WS_LDR = 129;   // row stride (doubles) of the result tile R[n][m] in LDS: both the column reads of the
-                              // direct pass and the row reads of the mirror pass are bank-conflict free
-constexpr size_t ws_smem_bytes() {
-  return (size_t)(2 * lds_stage(128) + 2 * lds_stage(64) + 64 * WS_LDR) * sizeof(double);
-}
-
-// sequence index -> tile of the BN-wide columns [c0, c1) in band-major order (SyrkMap, R > 0)
-template <int CPT>
-__device__ __forceinline__ void syrk_map_lookup(const SyrkMap& map, int sq, int& tm, int& tc) {
-  const int tiles = map.tiles;
-  int lo = 0, hi = map.nband;                // band_start[lo] <= sq < band_start[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (map.band_start[mid] <= sq) lo = mid; else hi = mid;
-  }
-  int sp = sq - map.band_start[lo];
-  const int r0 = (map.band0 + lo) * map.R, r1 = min(r0 + map.R, tiles);
-  const int cfull = max(min(map.c1, CPT * (r0 + 1)), map.c0);
-  const int nfull = (cfull - map.c0) * (r1 - r0);
-  if (sp < nfull) {
-    tc = map.c0 + sp / (r1 - r0);
-    tm = r0 + sp % (r1 - r0);
-  } else {
-    sp -= nfull;
-    tc = cfull;
-    while (sp >= r1 - tc / CPT) { sp -= r1 - tc / CPT; ++tc; }
-    tm = tc / CPT + sp;
-  }
-}
-
-// HALF = k-tiles per pass of the epilogue (K = 32 HALF: 128, 256, 512, 1024)
-template <int HALF>
-__global__ __launch_bounds__(512, 1) void syrk_mirror_ws_kernel(GemmOperands g, double alpha, double* __restrict__ C,
-                                                                int64_t ldc, SyrkMap map, int nt) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int A_STAGE = lds_stage(128), B_BASE = 2 * lds_stage(128), B_STAGE = lds_stage(64);
-  constexpr int NKT = 2 * HALF;              // k-tiles per tile
-  constexpr int PER = 32 / HALF;             // elements per epilogue thread and chunk (8, 4, 2, 1)
-  double* Rt = smem + 2 * lds_stage(128) + 2 * lds_stage(64);
-  const int tid = threadIdx.x;
-  const bool compute = tid < 256;
-  const int M = g.M;
-  // this workgroup's tiles: positions s0 + li, s0 + li + per, ... of its XCD's contiguous share of the sequence
-  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int q = nt / 8, rem = nt % 8;
-  const int s0 = xcd * q + min(xcd, rem), s1 = s0 + q + (xcd < rem ? 1 : 0);
-
-  // ---- compute-wave state ---------------------------------------------------------------------------
-  const int lane = tid & 63, wave = (tid >> 6) & 3;
-  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
-  const int lm = lane & 15, lk = lane >> 4;
-  d4 acc[4][2];
-  double ra[2][8], rb[2][4];                 // two operand k-tiles in flight (register sets by parity)
-  // The operand tiles are loaded and staged by the EPILOGUE waves (thread e = tid - 256): a compute wave is alone on
-  // its SIMD, so everything it does besides MFMA (address arithmetic, waiting for loads, LDS stores) is MFMA idle time.
-  const int ax = tid & 127, bx = tid & 63;
-  // wave-uniform parts of the thread index as scalars: the column pointers below are then uniform (SGPR base +
-  // one 32-bit lane offset per load instead of a 64-bit address per element)
-  const int akb = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);   // A tile: 128 x 16, element (ax, akb + 2 q)
-  const int bkb = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // B tile:  64 x 16, element (bx, bkb + 4 q)
-  auto load_ktile = [&](int m0, int n0, int kt, double (&xa)[8], double (&xb)[4]) {
-    const int arow = min(ax, M - 1 - m0), brow = min(bx, M - 1 - n0);
-    const double* pa = g.A + (int64_t)(kt * BK + akb) * g.lda + m0;
-    const double* pb = g.B + (int64_t)(kt * BK + bkb) * g.ldb + n0;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) xa[qq] = (pa + (int64_t)(2 * qq) * g.lda)[arow];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) xb[qq] = (pb + (int64_t)(4 * qq) * g.ldb)[brow];
-  };
-  auto stage_ktile = [&](int st, const double (&xa)[8], const double (&xb)[4]) {
-    double* as = smem + st * A_STAGE;
-    double* bs = smem + B_BASE + st * B_STAGE;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) as[lds_at<true, 128>(akb + 2 * qq, ax)] = xa[qq];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) bs[lds_at<true, 64>(bkb + 4 * qq, bx)] = xb[qq];
-  };
-  auto mfma_ktile = [&](int st) {
-    const double* as = smem + st * A_STAGE;
-    const double* bs = smem + B_BASE + st * B_STAGE;
-    double af[2][4], bf[2][2];               // the fragments of the next k-step are read before this step's MFMAs
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[0][i] = as[lds_at<true, 128>(lk, wm + i * 16 + lm)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bf[0][j] = bs[lds_at<true, 64>(lk, wn + j * 16 + lm)];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      const int cur = (kk >> 2) & 1;
-      if (kk + 4 < BK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[cur ^ 1][i] = as[lds_at<true, 128>(kk + 4 + lk, wm + i * 16 + lm)];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[cur ^ 1][j] = bs[lds_at<true, 64>(kk + 4 + lk, wn + j * 16 + lm)];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // ---- epilogue-wave state ----------------------------------------------------------------------------
-  const int e = tid - 256;                   // 0 .. 255 for the epilogue waves
-  const int drow = e & 127;                  // direct pass: a wave = 64 consecutive rows of one column (512 bytes)
-  const int dcs = __builtin_amdgcn_readfirstlane((e >> 7) & 1);
-  const int mn = e & 63;                     // mirror pass: a wave = the 64 rows of one mirrored column
-  const int mms = __builtin_amdgcn_readfirstlane((e >> 6) & 3);
-  double cold[1][PER];                       // C values of the next direct chunk (loaded one k-tile ahead)
-  // C loads of direct chunk `chunk` of the tile at (tm0, tn0): never predicated (clamped, valid addresses); the
-  // column pointers are uniform
-  auto epi_load = [&](int tm0, int tn0, int chunk, double (&cv)[PER]) {
-    const int ro = min(drow, M - 1 - tm0);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = chunk * (2 * PER) + dcs + 2 * i;
-      cv[i] = (C + (int64_t)min(tn0 + c, M - 1) * ldc + tm0)[ro];
-    }
-  };
-  // direct pass: C[m0 + row, n0 + col] += alpha R, rows >= columns only; the sum goes back into R for the mirror
-  auto epi_direct = [&](int tm0, int tn0, int chunk, const double (&cv)[PER]) {
-    const bool rok = tm0 + drow < M;
-    const int dd = tm0 - tn0 + drow;         // row - column of element (drow, c) is dd - c
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = chunk * (2 * PER) + dcs + 2 * i;
-      const double v = cv[i] + alpha * Rt[c * WS_LDR + drow];
-      Rt[c * WS_LDR + drow] = v;
-      if (rok && tn0 + c < M && dd >= c) (C + (int64_t)(tn0 + c) * ldc + tm0)[drow] = v;
-    }
-  };
-  // mirror pass: C[n0 + nn, m0 + mm] = the updated C[m0 + mm, n0 + nn] for mm > nn (strictly below the diagonal)
-  auto epi_mirror = [&](int tm0, int tn0, int chunk) {
-    const bool nok = tn0 + mn < M;
-    const int dd = tn0 - tm0 + mn;           // element (mm, mn) is strictly below the diagonal when mm > dd
-    double v[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) v[i] = Rt[mn * WS_LDR + chunk * (4 * PER) + mms + 4 * i];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int mm = chunk * (4 * PER) + mms + 4 * i;
-      if (nok && tm0 + mm < M && mm > dd) (C + (int64_t)(tm0 + mm) * ldc + tn0)[mn] = v[i];
-    }
-  };
-
-  int s = s0 + li;
-  int gk = 0;                                // global k-tile counter: LDS stage = gk & 1
-  bool have_cur = s < s1;
-  int tm = 0, tc = 0, m0 = 0, n0 = 0;
-  int tmn = 0, tcn = 0;
-  bool have_next = false;
-  if (have_cur) {
-    syrk_map_lookup<2>(map, s, tm, tc);
-    m0 = tm * 128;
-    n0 = tc * 64;
-    have_next = s + per < s1;
-    if (have_next) syrk_map_lookup<2>(map, s + per, tmn, tcn);
-    if (!compute) {
-      load_ktile(m0, n0, 0, ra[0], rb[0]);
-      load_ktile(m0, n0, 1, ra[1], rb[1]);
-      stage_ktile(0, ra[0], rb[0]);          // (register set 0 is free again: k-tile 2 goes there)
-    }
-  }
-  __syncthreads();
-  bool have_prev = false;
-  int pm0 = 0, pn0 = 0;
-  while (have_cur || have_prev) {
-    if (compute && have_cur) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    }
-    // k-tiles two at a time: the operand register set of a k-tile is its parity (NKT is even, so the parities line up
-    // across tiles); two k-tiles are in flight
-    for (int kt = 0; kt < NKT; kt += 2, gk += 2) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = kt + h;
-        if (compute) {
-          if (have_cur) mfma_ktile((gk + h) & 1);
-        } else {
-          if (have_cur) {
-            // k-tile k + 2 of the sequence: in this tile, or one of the first two of the next tile
-            if (k + 2 < NKT) load_ktile(m0, n0, k + 2, ra[h], rb[h]);
-            else if (have_next) load_ktile(tmn * 128, tcn * 64, k + 2 - NKT, ra[h], rb[h]);
-          }
-          if (have_prev) {
-            if (k < HALF) {
-              epi_direct(pm0, pn0, k, cold[0]);
-              if (k + 1 < HALF) epi_load(pm0, pn0, k + 1, cold[0]);    // in flight during the next k-tile
-            } else {
-              epi_mirror(pm0, pn0, k - HALF);
-            }
-          }
-          // the C values of the CURRENT tile's first chunk: in flight until that tile's epilogue starts
-          if (k == NKT - 1 && have_cur) epi_load(m0, n0, 0, cold[0]);
-          // k-tile k + 1 (loaded one k-tile ago into the other set) goes to the other LDS stage
-          if (have_cur && (k + 1 < NKT || have_next)) stage_ktile((gk + h + 1) & 1, ra[h ^ 1], rb[h ^ 1]);
-        }
-        __syncthreads();
-      }
-    }
-    // hand the accumulators over: R[n][m] (the previous tile's epilogue has finished reading R)
-    if (compute && have_cur) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) Rt[(wn + j * 16 + lk + 4 * r) * WS_LDR + wm + i * 16 + lm] = acc[i][j][r];
-    }
-    __syncthreads();
-    have_prev = have_cur;
-    pm0 = m0;
-    pn0 = n0;
-    s += per;
-    have_cur = have_next;
-    m0 = tmn * 128;
-    n0 = tcn * 64;
-    have_next = have_cur && s + per < s1;
-    if (have_next) syrk_map_lookup<2>(map, s + per, tmn, tcn);
-  }
-}
-
 // Host side of SyrkMap: the BN-wide columns [c0, c1) of the lower tile triangle (tile rows from the diagonal down).
 // rows_per_band == 0: the column-by-column order (development switch BIGKRLS_SYRK_ORDER=cols).
 template <int SBN>
@@ -1023,30 +812,9 @@ static int launch_syrk_mirror(bigkrls_ctx* ctx, const GemmOperands& g, double al
   SyrkMap mp;
   const int64_t nt = syrk_map_build<SBN>(mp, tiles, c0, c1, g.K);
   if (nt <= 0) return BIGKRLS_OK;
-  // BIGKRLS_SYRK=ws: the wave-specialised persistent kernel (128 x 64 tiles, accumulating updates with k a multiple
-  // of 32 in [128, 1024], enough tiles to give every workgroup several)
-  const char* ws_env = getenv("BIGKRLS_SYRK");
-  const bool ws_mode = ws_env && std::string(ws_env) == "ws";
-  if (ws_mode && SBN == 64 && ACCUM && mp.R > 0 && (g.K == 128 || g.K == 256 || g.K == 512 || g.K == 1024)) {
-    int ncu = 0;
-    BK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    const int nwg = ncu / 8 * 8;
-    if (nwg >= 8 && nt >= 4 * (int64_t)nwg) {
-      const void* kern = g.K == 128 ? (const void*)syrk_mirror_ws_kernel<4>
-                         : g.K == 256 ? (const void*)syrk_mirror_ws_kernel<8>
-                         : g.K == 512 ? (const void*)syrk_mirror_ws_kernel<16> : (const void*)syrk_mirror_ws_kernel<32>;
-      BK_TRY(ensure_dyn_smem(ctx, kern, ws_smem_bytes()));
-      const dim3 grid((unsigned)nwg), block(512);
-      if (g.K == 128) hipLaunchKernelGGL(syrk_mirror_ws_kernel<4>, grid, block, ws_smem_bytes(), ctx->stream, g, alpha, C, ldc, mp, (int)nt);
-      else if (g.K == 256) hipLaunchKernelGGL(syrk_mirror_ws_kernel<8>, grid, block, ws_smem_bytes(), ctx->stream, g, alpha, C, ldc, mp, (int)nt);
-      else if (g.K == 512) hipLaunchKernelGGL(syrk_mirror_ws_kernel<16>, grid, block, ws_smem_bytes(), ctx->stream, g, alpha, C, ldc, mp, (int)nt);
-      else hipLaunchKernelGGL(syrk_mirror_ws_kernel<32>, grid, block, ws_smem_bytes(), ctx->stream, g, alpha, C, ldc, mp, (int)nt);
-      BK_CHECK_LAUNCH();
-      return BIGKRLS_OK;
-    }
-  }
-  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN, ACCUM>, smem_bytes_nt(SBN)));
-  hipLaunchKernelGGL((syrk_mirror_kernel<SBN, ACCUM>), dim3((unsigned)nt), dim3(NT), smem_bytes_nt(SBN), ctx->stream, g,
+  constexpr size_t smem = (SBN == 64 && SYRK64_LDS_EXACT) ? smem_bytes_nt(SBN) : smem_bytes(SBN);
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)syrk_mirror_kernel<SBN, ACCUM>, smem));
+  hipLaunchKernelGGL((syrk_mirror_kernel<SBN, ACCUM>), dim3((unsigned)nt), dim3(NT), smem, ctx->stream, g,
                      alpha, C, ldc, mp);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
