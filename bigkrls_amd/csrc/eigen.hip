@@ -2313,10 +2313,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int64_t maxb = (N + 255) / 256 + 2;
     const int64_t nmail1 = 2 * maxb * 2 * S2_B;  // pq_resident: 2 buffers x workgroups x 64 word pairs
     const int64_t nmail = nmail1 + 2 * 16 * 2 * S2_B;   // + 2 buffers x 16 group boxes
+    const int64_t npqc = PQC_MAIL_DOUBLES;   // pq_chol mailbox
     const int64_t npart = 2 * maxb + 2 * maxb * S2_B + S2_B + S2_B * S2_B + 2 * N + nmail;
     const int64_t ntall = (N / S2_B + 2) * S2_B * S2_B;
     const int64_t nfpart = (N / (S1F_CHUNKS * S2_B) + 3) * S2_B * S2_B;   // partial V'Y blocks of the fused small products
-    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + nfpart + 2 * N /*taus1, scales1*/ +
+    const int64_t need = 7 * nb64 + 8 * S2_B * S2_B + npart + ntall + nfpart + npqc + 2 * N /*taus1, scales1*/ +
                          (int64_t)S2_LD * N /*AB*/ + N + 8 /*soff as int64*/;
     BK_TRY(ws_get(ctx, SLOT_EIG_BT, need * sizeof(double), &p2));
     double* q = (double*)p2;
@@ -2336,6 +2337,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     }
     s1.Tall = q; q += ntall;
     s1.fpart = q; q += nfpart;
+    s1.pqc = q; q += npqc;
+    s1.fallback = (int*)scratch + 4;
+    if (mode != EIG_RESUME) {
+      BK_HIP(hipMemsetAsync(s1.pqc, 0, npqc * sizeof(double), st));
+      BK_HIP(hipMemsetAsync(s1.fallback, 0, sizeof(int), st));
+    }
     taus1 = q; q += 2 * N;
     AB = q; q += (int64_t)S2_LD * N;
     d_soff = (int64_t*)q;
