@@ -2376,6 +2376,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     }
     tick("setup + copy");
     if (mode == EIG_FULL) BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
+    if (mode == EIG_FULL && getenv("BIGKRLS_VERBOSE") && s1.pqc) {
+      double nfb = 0.0;
+      BK_HIP(hipMemcpyAsync(&nfb, s1.pqc + PQC_OFF_SLICES + PQC_NG + 32, sizeof(double), hipMemcpyDeviceToHost, st));
+      BK_HIP(hipStreamSynchronize(st));
+      fprintf(stderr, "[bigkrls]   panels left to the Householder kernel by pq_chol: %d\n", (int)nfb);
+    }
     {
       // watchdog word of the register-resident panel QR: checked before stage 2 consumes the band
       int h_err1 = 0;

@@ -12,7 +12,8 @@ zs = [e for e in s1 if "s1_fused_z" in e[2]]
 out = []
 for i, z in enumerate(zs):
     nxt = zs[i + 1][0] if i + 1 < len(zs) else t_end
-    pq = [e for e in s1 if "pq_resident" in e[2] and z[1] <= e[0] < nxt]
+    pq = [e for e in s1 if ("pq_chol" in e[2] or "pq_resident" in e[2]) and z[1] <= e[0] < nxt]
+    if pq: pq = [(pq[0][0], max(e[1] for e in pq), "pq")]
     sy = [e for e in s1 if "syrk_mirror" in e[2] and z[1] <= e[0] < nxt]
     av = [e for e in s1 if "gemm_kernel<false, false, 64>" in e[2] and z[1] <= e[0] < nxt]
     if not pq or not sy: continue
