@@ -396,17 +396,20 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
             if ms <= 0:
                 return None
             gbs = (by / 1e9) / (ms / 1e3)
-            return {"kernel": "pq_resident: register-resident Householder QR of one m x 64 panel (stage 1), one launch "
-                              "per panel on the look-ahead stream, concurrent with syrk_mirror_kernel",
+            return {"kernel": "pq_chol (+ pq_resident as its fallback): register-resident factorisation of one m x 64 panel "
+                              "(stage 1) by CholeskyQR2 + Householder reconstruction, one launch per panel on the "
+                              "look-ahead stream, concurrent with syrk_mirror_kernel",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches_sampled": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
                     "total_ms_per_fit": round(ms * STRIDE / args.steps, 2), "concurrent": True,
                     "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
                     "note": "achieved = algorithmic bytes (panel read + written once, V written once: 24 m b) / "
-                            "HIP-event duration on the look-ahead stream. The kernel is bound by 64 dependent "
-                            "all-to-all exchanges of partial sums between its workgroups (~6-11 us each), and its "
-                            "duration is hidden behind the trailing update it runs concurrently with"}
+                            "HIP-event duration on the look-ahead stream (both launches: pq_resident returns at once "
+                            "unless pq_chol left the panel to it). The kernel is a chain of latencies -- two "
+                            "all-reduces of a 64 x 64 Gram matrix and one broadcast between its workgroups, three "
+                            "64 x 64 factorisations inside each -- not of bytes; beside the trailing update it starts "
+                            "only where an update workgroup has ended (256 registers per lane, 107 KB of LDS)"}
 
         def hbm_entry(name, kernel, note, flops_per_byte=None):
             ms, by, cnt = prof[name]

@@ -2353,7 +2353,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
     if (mode != EIG_RESUME) BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
-    if (mode == EIG_FULL && n >= 14848 + 4 * S2_B) {
+    if (mode == EIG_FULL && n >= S1_AGG_MIN_M + 4 * S2_B) {
       // reflector blocks of the two panel groups whose trailing update is pending (stage1_to_band)
       void* pagg = nullptr;
       const int64_t blk = N * 4 * S2_B;
