@@ -448,7 +448,7 @@ def test_lanczos_sampled_verification_matches_full_rayleigh_ritz(ctx, monkeypatc
 
 
 def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatch):
-    """Stage 1 above 14848 trailing rows applies the trailing update for two panels at once (k = 256),
+    """Stage 1 above 10752 trailing rows applies the trailing update for two panels at once (k = 256),
     as two pieces of equal area with thin corrections of everything that reads the stale matrix
     (csrc/eigen_2stage.inc, "aggregated phase"). n = 15700 runs a few groups of it plus the hand-over to
     one update per panel; BIGKRLS_S1AGG=0 is the plain loop. Same eigenvalues to rounding, kept
@@ -467,3 +467,56 @@ def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatc
     assert rel(agg.values, plain.values) < 1e-13
     res, orth = eigen_quality(ops, K, agg.vectors, agg.values)
     assert res < 1e-11 and orth < 1e-11 and abs(agg.values.sum() - n) < 1e-11 * n
+
+
+def test_panel_factorisation_by_choleskyqr_matches_householder_kernel(ctx, monkeypatch):
+    """Stage-1 panels are factorised by CholeskyQR2 + Householder reconstruction (pq_chol, csrc/eigen_2stage.inc);
+    BIGKRLS_PQ=householder runs the 64-exchange Householder kernel (pq_resident) on every panel instead. Same
+    eigenvalues to rounding, kept eigenvectors with residual and orthogonality at rounding level -- on a kernel
+    matrix that crosses the aggregated phase and the hand-over (n = 12 200), and on a numerically singular one
+    (P = 2: the later panels' Gram matrices are not positive definite, pq_chol leaves them to pq_resident)."""
+    from bigkrls_amd import ops
+    from bigkrls_amd.synth import synth
+    for n, p, seed in ((12200, 9, 17), (2100, 2, 5)):
+        X, _ = synth(n, p, seed)
+        Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+        K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+        monkeypatch.setenv("BIGKRLS_PQ", "householder")
+        hh = ops.bEigen(K, None, 0.001)
+        monkeypatch.delenv("BIGKRLS_PQ")
+        ch = ops.bEigen(K, None, 0.001)
+        assert ch.lastkeeper == hh.lastkeeper
+        assert rel(ch.values, hh.values) < 1e-13
+        res, orth = eigen_quality(ops, K, ch.vectors, ch.values)
+        assert res < 1e-11 and orth < 1e-11 and abs(ch.values.sum() - n) < 1e-11 * n
+
+
+def test_ill_conditioned_panels_fall_back_to_the_householder_kernel():
+    """pq_chol leaves a panel whose Gram matrix has no safe Cholesky factor to pq_resident (launched behind it): on a
+    rank-3 matrix every panel after the first ones does; BIGKRLS_VERBOSE reports the count (a process of its own: the
+    library reads the variable at every call, the count goes to stderr)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+import bigkrls_amd as bk
+from bigkrls_amd import ops
+rng = np.random.default_rng(3)
+n = 1800
+U = rng.standard_normal((n, 3))
+A = U @ U.T + 1e-14 * np.eye(n)
+ctx = bk.Context(0)
+e = ops.bEigen(ctx.from_numpy(np.asfortranarray(A)), None, 0.0)
+v = np.asarray(e.values).ravel()
+ref = np.linalg.eigvalsh(A)[::-1]
+print("max eigenvalue error", float(np.abs(v - ref).max() / ref[0]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BIGKRLS_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    err = float(r.stdout.strip().split()[-1])
+    assert err < 1e-13, r.stdout
+    counts = [int(ln.split(":")[-1]) for ln in r.stderr.splitlines() if "panels left to the Householder kernel by pq_chol" in ln]
+    assert counts and counts[0] > 0, r.stderr[-2000:]
