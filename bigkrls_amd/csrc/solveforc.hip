@@ -168,6 +168,37 @@ static double ratio_sum(const double* d, int64_t n, double t) {
   for (int64_t i = 0; i < n; ++i) s += (long double)(d[i] / (d[i] + t));
   return (double)s;
 }
+// The same sum in plain double with four accumulators (vectorisable: ~5x faster than the dependent extended-precision
+// chain): used only to FIND the neighbourhood of the step at which a loop stops; the step itself is then settled with
+// the exact sum (ratio_sum) on either side of it.
+static double ratio_sum_fast(const double* d, int64_t n, double t) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int64_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    s0 += d[i] / (d[i] + t);
+    s1 += d[i + 1] / (d[i + 1] + t);
+    s2 += d[i + 2] / (d[i + 2] + t);
+    s3 += d[i + 3] / (d[i + 3] + t);
+  }
+  for (; i < n; ++i) s0 += d[i] / (d[i] + t);
+  return (s0 + s1) + (s2 + s3);
+}
+// smallest s in [1, smax] with stop(s) true, given stop(0) false and stop monotone (false ... false true ... true):
+// located with `guess` (a cheap approximation of stop), settled with `stop` itself
+template <class Guess, class Stop>
+static int64_t first_stop(int64_t smax, Guess guess, Stop stop) {
+  int64_t lo = 0, hi = 1;                      // guess false at lo
+  while (hi < smax && !guess(hi)) { lo = hi; hi *= 2; }
+  if (hi > smax) hi = smax;
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (guess(mid)) hi = mid; else lo = mid;
+  }
+  int64_t s = hi;                              // the exact predicate decides: walk to its first true step
+  while (s > 1 && stop(s - 1)) --s;
+  while (s < smax && !stop(s)) ++s;
+  return s;
+}
 
 int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, double* U) {
   BK_REQUIRE(vals && n_vals > 0 && L && U, "lambda_bounds: bad arguments");
@@ -177,26 +208,18 @@ int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, doub
       return BIGKRLS_EINVAL;
     }
   // U <- n; while (sum(d/(d+U)) < 1) U <- U - 1        (:17-21)
-  // The sum is monotone decreasing in U, so the first U (counting down from n) with
-  // sum >= 1 is found by bisection over the integer step count; the loop's own
-  // arithmetic (U - 1 repeatedly, exact for integers) is reproduced.
+  // The sum is monotone decreasing in U, so the first U (counting down from n) with sum >= 1 is a search over the
+  // integer step count; the loop's own arithmetic (U - 1 repeatedly, exact for integers) is reproduced.
   {
-    double u = (double)n;
+    const double u = (double)n;
     if (!(ratio_sum(vals, n_vals, u) < 1.0)) {
       *U = u;
     } else {
-      // find smallest s >= 1 with sum(d/(d+(n-s))) >= 1; guard at U -> 0
-      int64_t lo = 0, hi = 1;  // predicate false at lo (sum < 1), search hi where true
-      while (hi < n && ratio_sum(vals, n_vals, (double)(n - hi)) < 1.0) {
-        lo = hi;
-        hi *= 2;
-      }
-      if (hi > n) hi = n;  // U = 0: sum = n_vals positive terms = count >= 1
-      while (hi - lo > 1) {
-        const int64_t mid = lo + (hi - lo) / 2;
-        if (ratio_sum(vals, n_vals, (double)(n - mid)) < 1.0) lo = mid; else hi = mid;
-      }
-      *U = (double)(n - hi);
+      // step s: U = n - s; at s = n (U = 0) the sum is the count of positive terms >= 1
+      const int64_t s = first_stop(
+          n, [&](int64_t k) { return !(ratio_sum_fast(vals, n_vals, (double)(n - k)) < 1.0); },
+          [&](int64_t k) { return !(ratio_sum(vals, n_vals, (double)(n - k)) < 1.0); });
+      *U = (double)(n - s);
     }
   }
   // L <- eps; q <- which.min(abs(d - max(d)/1000)); while (sum(d/(d+L)) > q) L <- L + 0.05  (:28-33)
@@ -220,18 +243,11 @@ int lambda_bounds(const double* vals, int64_t n_vals, int64_t n, double* L, doub
     if (!(ratio_sum(vals, n_vals, L_at(0)) > q)) {
       *L = L_at(0);
     } else {
-      int64_t lo = 0, hi = 1;
-      const int64_t cap = (int64_t)1 << 40;
-      while (hi < cap && ratio_sum(vals, n_vals, L_at(hi)) > q) {
-        lo = hi;
-        hi *= 2;
-        if (hi > (1 << 28)) break;  // L > 1.3e7: sum is far below any q >= 1 long before this
-      }
-      while (hi - lo > 1) {
-        const int64_t mid = lo + (hi - lo) / 2;
-        if (ratio_sum(vals, n_vals, L_at(mid)) > q) lo = mid; else hi = mid;
-      }
-      *L = L_at(hi);
+      const int64_t cap = (int64_t)1 << 28;   // L > 1.3e7: the sum is far below any q >= 1 long before this
+      const int64_t s = first_stop(
+          cap, [&](int64_t k) { return !(ratio_sum_fast(vals, n_vals, L_at(k)) > q); },
+          [&](int64_t k) { return !(ratio_sum(vals, n_vals, L_at(k)) > q); });
+      *L = L_at(s);
     }
   }
   return BIGKRLS_OK;
