@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="route a single-GPU run through the row-block path (bigkrls_amd.dist) under an RCCL group "
                          "of size 1: exercises exactly the code of --gpus N > 1 on one GPU")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the --gpus N rank processes, let them rendezvous over gloo on the CPU and build the "
+                         "library's rank objects over host buffers -- no GPU, no fit: checks the launch path only")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     custom = False
@@ -213,12 +216,138 @@ class CpuBaseline:
         return res
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _visible_gpus():
+    """Devices a rank process will see, counted by a short-lived child (this process never loads the HIP runtime)."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: this process starts the N ranks itself -- the reference's
+    parallel path also starts its own workers (R/bigKRLS.R:340-343, makeCluster(Ncores)) -- as N children of THIS
+    program with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run would set), relays rank 0's
+    JSON line as its last line of stdout and exits non-zero if any rank fails. It never touches the GPU and never
+    re-executes itself. Fewer visible devices than N is an error, not a silent one-GPU run."""
+    n = args.gpus
+    if not args.dry_launch:
+        have = _visible_gpus()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible "
+                  f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}); not running on fewer", file=sys.stderr)
+            return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   BIGKRLS_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    # a rank that dies leaves its peers inside a collective: end them (these exact PIDs) as soon as one has failed
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        time.sleep(0.05)
+    if failed is not None:
+        t_end = time.time() + 15.0
+        for r in sorted(live):
+            while procs[r].poll() is None and time.time() < t_end:
+                time.sleep(0.1)
+            if procs[r].poll() is None:
+                procs[r].kill()
+            procs[r].wait()
+    reader.join(timeout=10.0)
+    lines = [ln.rstrip("\n") for ln in out0 if ln.strip()]
+    json_line = next((ln for ln in reversed(lines) if ln.lstrip().startswith("{")), None)
+    for ln in lines:
+        if ln is not json_line:
+            print(ln, file=sys.stderr)
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        return 1
+    if json_line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(json_line, flush=True)
+    return 0
+
+
+def dry_rank(args, world, rank):
+    """One rank of `--dry-launch`: rendezvous over gloo, the library's rank object over host buffers
+    (bigkrls_comm_create_callbacks with no context), its rank count read back, one collective through it, and the
+    rows this rank would own in the fit. No GPU is touched."""
+    import ctypes as C
+    import numpy as np
+    import torch.distributed as dist
+    from bigkrls_amd import _lib, dist as bkdist
+
+    if os.environ.get("BIGKRLS_DRY_FAIL_RANK") == str(rank):      # tests: a rank that dies before the rendezvous
+        return 3
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = bkdist.comm_callbacks(None)
+    r, w = comm.rank_count()
+    count = 3
+    buf = np.zeros((4 + world) * count)
+    buf[0:count] = 1.0
+    _lib.call("bigkrls_comm_check", comm.handle, buf.ctypes.data_as(C.c_void_p), count)
+    cfg = args.cfg
+    opt = _lib.FitOptions()
+    opt.struct_bytes = C.sizeof(_lib.FitOptions)
+    opt.neig = cfg["neig"] or 0
+    r0, r1 = C.c_int64(-1), C.c_int64(-1)
+    _lib.call("bigkrls_fit_dist_rows", comm.handle, cfg["n"], C.byref(opt), C.byref(r0), C.byref(r1))
+    rows = [None] * world
+    dist.all_gather_object(rows, [int(r0.value), int(r1.value)])
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "comm_nranks": int(w), "comm_rank": int(r),
+                          "ranks_in_allreduce": int(buf[0]), "rows": rows,
+                          "self_launched": bool(os.environ.get("BIGKRLS_BENCH_SELF_LAUNCHED")),
+                          "config": {"name": cfg["name"], "n": cfg["n"], "p": cfg["p"]}}), flush=True)
+    return 0
+
+
 def main():
     args = parse()
     cfg = args.cfg
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))           # before anything here imports torch or touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a launcher that started another number of ranks than --gpus says: refuse, a line with the wrong n_gpus is worse
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_launch:
+        sys.exit(dry_rank(args, world, rank))
     # ---- CPU-baseline child: started before anything here touches the GPU ------------------------
     cpu = None
     cpu_n = args.cpu_n if args.cpu_n is not None else (cfg["n"] if cfg["n"] <= 20000 else None)
@@ -229,6 +358,10 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if world > 1 and torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)",
+              file=sys.stderr)
+        sys.exit(2)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
@@ -238,8 +371,6 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     try:
         res = run(args, cfg, world, rank, local_rank, np, torch, dist)
@@ -283,11 +414,18 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     if world > 1 or args.force_dist:
         from bigkrls_amd import dist as bkdist
 
+        comm = bkdist.get_comm(ctx)
+        comm_rank, comm_nranks = comm.rank_count()        # read back from the library's rank object (bigkrls_comm_rank)
+        if (comm_rank, comm_nranks) != (rank, world):
+            raise RuntimeError(f"communicator says rank {comm_rank} of {comm_nranks}, launcher says {rank} of {world}")
+
         def one_fit(timings):
             # the same outputs as the single-GPU fit (the variance matrices are computed only when asked for): this
             # rank's column blocks of K, vcov.est.c, vcov.est.fitted
-            return bkdist.bigKRLS_dist(y, X, ctx=ctx, timings=timings, keep_outputs=True, **fit_kw)
+            return bkdist.bigKRLS_dist(y, X, ctx=ctx, comm=comm, timings=timings, keep_outputs=True, **fit_kw)
     else:
+        comm_nranks = None
+
         def one_fit(timings):
             return bk.bigKRLS(y, X, ctx=ctx, timings=timings, **fit_kw)
 
@@ -527,6 +665,21 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
         crit = [c for c in cands if not c.get("concurrent")]
         roof = max(crit or cands, key=lambda c: c["total_ms_per_fit"]) if cands else None
         tu_ms, tu_flops, tu_n = prof["trailing_update"]
+        # fit-level roofline: the flops the eigensolver cannot avoid / wall-clock of the WHOLE fit / fp64 MFMA peak.
+        # Dense path: tridiagonalisation 4N^3/3 + the two back-transforms of the kept columns 2 * 2 N^2 lastkeeper.
+        # Neig << N: the K B_j products and the re-orthogonalisation actually issued (from the library's counters).
+        if roof is not None:
+            if prof["lanczos_kb"][0] > 0:
+                fit_flops = (prof["lanczos_kb"][1] + prof["lanczos_cgs2"][1]) / args.steps
+                fit_flops_note = "sum of the K B_j and CGS2 flops of the block Lanczos (library counters)"
+            else:
+                fit_flops = 4.0 * n ** 3 / 3.0 + 2.0 * n * n * float(lastkeeper) * 2.0
+                fit_flops_note = "4N^3/3 (tridiagonalisation) + 2 * 2 N^2 lastkeeper (two back-transforms of the kept columns)"
+            roof = dict(roof)
+            roof["fit_flops"] = fit_flops
+            roof["fit_frac"] = round(fit_flops / sec_per_fit / (FP64_MFMA_PEAK_TFLOPS * 1e12), 4)
+            roof["fit_frac_note"] = ("fit_frac = fit_flops / value / fp64 MFMA peak, fit_flops = " + fit_flops_note +
+                                     "; the whole fit's wall-clock incl. everything that runs no MFMA")
         res = {
             # BASELINE.json: "bigKRLS() fit wall-clock + kernel-GEMM fp64 GFLOP/s at N=20000,P=20";
             # `value` is the wall-clock half, `kernel_gemm.gflops` the GEMM half
@@ -534,6 +687,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
             "value": round(sec_per_fit, 4),
             "unit": "s",
             "n_gpus": world,
+            "comm_nranks": comm_nranks,      # bigkrls_comm_rank of the RCCL communicator the fit ran on (null: bigkrls_fit)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(sec_per_fit * 1e3, 2),
@@ -566,7 +720,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                         "executes half of them and mirrors); for P <~ 40 the build is HBM-write bound (8 N^2 bytes, "
                         "AI = P/4 flop/B), so the binding roofline is hbm_write_gbs / 8000"},
             "roofline": roof,
-            "other_kernels": [c for c in cands if c is not roof] + extra,
+            "other_kernels": [c for c in cands if c["kernel"] != (roof or {}).get("kernel")] + extra,
         }
         if tu_ms > 0:
             res["trailing_update"] = {"tflops": round(tu_flops / (tu_ms / 1e3) / 1e12, 3), "launches": tu_n}

@@ -52,6 +52,12 @@ class Comm:
     def __init__(self, ctx: Optional[Context], handle, world: int, rank: int, kind: str, keep=None):
         self.ctx, self.handle, self.world, self.rank, self.kind, self._keep = ctx, handle, world, rank, kind, keep
 
+    def rank_count(self):
+        """(rank, nranks) as the library's rank object reports them (`bigkrls_comm_rank`)."""
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        _lib.call("bigkrls_comm_rank", self.handle, C.byref(r), C.byref(w))
+        return int(r.value), int(w.value)
+
     def close(self):
         if self.handle is not None:
             _lib.call("bigkrls_comm_destroy", self.handle)
