@@ -258,6 +258,11 @@ int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t l
 // mode: EIG_FULL decomposes A; EIG_SETUP_ONLY only lays out the workspace of the two-stage path
 // (used by the distributed stage 1); EIG_RESUME continues after an externally driven stage 1.
 enum EigMode { EIG_FULL = 0, EIG_SETUP_ONLY = 1, EIG_RESUME = 2 };
+// Internal status (never crosses the C ABI): the watchdog of a persistent kernel fired in a decomposition whose
+// stage 1 was driven from outside (EIG_RESUME). The distributed fit agrees on it over the ranks and replays the
+// decomposition with the launch-per-step kernels on every rank (csrc/fit.hip); larger than every public code so
+// that the agreement (a MAX) prefers it to a rank-local OK.
+constexpr int BK_EWATCHDOG = 90;
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
           int part_index = 0, int part_count = 1, int mode = EIG_FULL);

@@ -35,17 +35,22 @@ RcclApi& rccl() {
   std::call_once(once, [] {
     void* h = nullptr;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) {               // one that is already mapped first
-      h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
-      if (h) break;
-    }
-    if (!h)
-      for (const char* nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (const char* user = getenv("BIGKRLS_RCCL_LIB")) {   // an RCCL build of the caller's choice: that one or none
+      h = dlopen(user, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* nm : names) {             // one that is already mapped first
+        h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
         if (h) break;
       }
+      if (!h)
+        for (const char* nm : names) {
+          h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+          if (h) break;
+        }
+    }
     if (!h) {
-      api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      const char* e = dlerror();                   // (a second call would return NULL: the first one clears the state)
+      api.why = std::string("librccl not found: ") + (e ? e : "");
       return;
     }
     auto sym = [&](const char* nm) { return dlsym(h, nm); };
@@ -137,17 +142,19 @@ int comm_agree(bigkrls_comm* comm, int local_status) {
   std::string local_msg = local_status != BIGKRLS_OK ? std::string(bigkrls_last_error()) : std::string();
   double v = -(double)local_status;      // MIN of the negated codes = the largest code
   const int rc = comm_all_reduce_host(comm, &v, 1, COMM_MIN);
-  if (local_status != BIGKRLS_OK) {
-    set_error(local_msg);
-    return local_status;
+  if (rc != BIGKRLS_OK) {                // the collective itself failed: nothing was agreed
+    if (local_status != BIGKRLS_OK) set_error(local_msg);
+    return local_status != BIGKRLS_OK ? local_status : rc;
   }
-  if (rc != BIGKRLS_OK) return rc;
+  // EVERY rank returns the same (largest) code, also one that failed locally with a smaller one: what the caller
+  // does next -- give up, or replay the decomposition after BK_EWATCHDOG -- must be the same decision everywhere
   const int worst = (int)(-v + 0.5);
-  if (worst != BIGKRLS_OK) {
-    set_error("another rank of the multi-GPU fit failed with status " + std::to_string(worst));
-    return worst;
-  }
-  return BIGKRLS_OK;
+  if (worst == BIGKRLS_OK) return BIGKRLS_OK;
+  if (local_status == worst) set_error(local_msg);
+  else if (local_status != BIGKRLS_OK)
+    set_error(local_msg + " (and another rank of the multi-GPU fit failed with status " + std::to_string(worst) + ")");
+  else set_error("another rank of the multi-GPU fit failed with status " + std::to_string(worst));
+  return worst;
 }
 
 void dist_partition(int64_t n, int world, int64_t align, int rank, int64_t* nb, int64_t* r0, int64_t* r1) {
@@ -262,8 +269,8 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
     k += w;
   }
   BK_TRY(comm_agree(comm, status));
-  // stage 2, divide & conquer and this rank's slice of the back-transform; a fired watchdog of the distributed
-  // stage 1 cannot be replayed and comes back as an error -- on every rank
+  // stage 2, divide & conquer and this rank's slice of the back-transform; a fired watchdog of a persistent kernel
+  // (this rank's or another's) comes back as BK_EWATCHDOG on EVERY rank: the caller replays the decomposition
   int64_t nv = 0;
   void* pq = nullptr;
   status = eigen(ctx, nullptr, n, n, neig, dvals, neig, eigtrunc, dQ, n, &nv, rank, world, EIG_RESUME);

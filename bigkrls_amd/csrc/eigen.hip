@@ -2394,9 +2394,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       if (fault && std::string(fault) == "watchdog" && !ctx->no_resident) h_err1 = 1;
 #endif
       if (h_err1 != 0 && mode == EIG_RESUME) {
-        set_error("eigen: watchdog of the register-resident panel QR fired during the distributed stage 1; "
-                  "rerun with BIGKRLS_PQ=steps");
-        return BIGKRLS_EHIP;
+        set_error("eigen: watchdog of the register-resident panel QR fired during the distributed stage 1");
+        return BK_EWATCHDOG;     // the caller replays the decomposition on every rank (csrc/fit.hip)
       }
       if (h_err1 != 0) return eigen_retry_without_resident(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh,
                                                            vecs, ldv, h_n_vecs, part_index, part_count);
@@ -2463,8 +2462,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_HIP(hipEventRecord(ctx->ev_join, side));
     }
     if (h_err != 0 && mode == EIG_RESUME) {
-      set_error("eigen: watchdog of the LDS-resident bulge chasing fired; rerun with BIGKRLS_BC=wavefront");
-      return BIGKRLS_EHIP;
+      set_error("eigen: watchdog of the LDS-resident bulge chasing fired after the distributed stage 1");
+      return BK_EWATCHDOG;
     }
     if (h_err != 0)
       return eigen_retry_without_resident(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv,

@@ -290,8 +290,32 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     // the reduction overwrites its operand: it works on a copy of the column block
     void* pa = nullptr;
     BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_A, n * std::max<int64_t>(nloc, 1) * (int64_t)sizeof(double), &pa)));
-    if (nloc > 0) BK_HIP(hipMemcpyAsync(pa, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st));
-    BK_TRY(eigen_dense_dist(comm, (double*)pa, n, nb, neig, eigtrunc, dvals, dQ, &lastkeeper));
+    // A fired watchdog of a persistent kernel (panel factorisation / bulge chasing: their workgroups must be
+    // co-resident, and here they share the GPU with the collectives' kernels) is agreed on by all ranks inside
+    // eigen_dense_dist and the decomposition is redone ONCE, on every rank, with the launch-per-step kernels --
+    // K[:, r0:r1) is untouched, so the replay starts from a fresh copy (the single-GPU eigen() does the same).
+    int rc_e = BIGKRLS_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (nloc > 0 && hipMemcpyAsync(pa, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        ctx->no_resident = false;
+        set_error("fit: copy of the column block of K failed");
+        return BIGKRLS_EHIP;
+      }
+      rc_e = eigen_dense_dist(comm, (double*)pa, n, nb, neig, eigtrunc, dvals, dQ, &lastkeeper);
+      if (rc_e != BK_EWATCHDOG || attempt == 1 || ctx->no_resident) break;
+      if (getenv("BIGKRLS_VERBOSE"))
+        fprintf(stderr, "[bigkrls] rank %d: persistent-kernel watchdog fired on some rank; replaying the distributed "
+                        "decomposition with per-step launches\n", comm->rank);
+      if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+      (void)hipStreamSynchronize(st);
+      ctx->no_resident = true;
+    }
+    ctx->no_resident = false;
+    if (rc_e == BK_EWATCHDOG) {
+      set_error(std::string(bigkrls_last_error()) + " (also after the replay with per-step launches)");
+      rc_e = BIGKRLS_EHIP;
+    }
+    BK_TRY(rc_e);
   } else {
     // tiny problems: K gathered (its column blocks are row blocks of K' = K), the decomposition replicated with the
     // back-transform split by eigenvector column, Q assembled by an all-reduce (sum)

@@ -1,4 +1,4 @@
-"""R's serialisation format (XDR, version 2) -- enough of it to write and read the `estimates.RData` that
+"""R's serialisation format (XDR; written as version 2, read as version 2 or 3) -- enough of it to write and read the `estimates.RData` that
 save.bigKRLS / load.bigKRLS exchange (R/bigKRLS.R:901-945, 960-1020; `save(bigKRLS_out, file = ...)` at
 R/bigKRLS.R:495 and R/bigKRLS_Rcpp_functions.R:311, `load()` at :349).
 
@@ -12,6 +12,13 @@ field from bit 12 -- followed by the type's payload; symbols are written once an
 that the reference tree holds, build/vignette.rds (a data.frame written by R 3.3.3), is kept as
 tests/golden/r_serialize_v2_vignette_index.rds: the reader must parse it and the writer must reproduce its
 stream byte for byte (tests/test_rdata.py).
+
+Version 3 (the default of `save()` / `saveRDS()` since R 3.5; magic "RDX3\n") differs for data in two ways, both
+handled by the reader: the header also carries the native encoding's name, and vectors may arrive as ALTREP items
+(type 238: a class description, a state, attributes) -- the compact integer / real sequences (`1:n`), the `wrap_*`
+classes (a vector plus sortedness metadata) and deferred `as.character(<numbers>)` are expanded, any other ALTREP
+class is refused by name. The writer always emits version 2, which every R since 2.3.0 loads; no R session was
+available here, so files written by R >= 3.5 are covered by hand-assembled version-3 streams only.
 
 Objects: R vectors map to `RVec(kind, values, attrs)` with kind in {"lgl", "int", "real", "str", "list"};
 NULL is None. `from_python` / `to_python` convert between that tree and plain Python (dict = named list,
@@ -27,11 +34,12 @@ from typing import Any, List, Optional, Tuple
 import numpy as np
 
 NILSXP, SYMSXP, LISTSXP, CHARSXP, LGLSXP, INTSXP, REALSXP, STRSXP, VECSXP = 0, 1, 2, 9, 10, 13, 14, 16, 19
-REFSXP, NILVALUE_SXP = 255, 254
+REFSXP, NILVALUE_SXP, ALTREP_SXP = 255, 254, 238
 IS_OBJECT, HAS_ATTR, HAS_TAG = 0x100, 0x200, 0x400
 GP_ASCII, GP_UTF8 = 0x40 << 12, 0x08 << 12
 NA_INT = -2 ** 31
 _NA_REAL_BYTES = struct.pack(">II", 0x7FF00000, 1954)         # R's NA_real_: a NaN whose low word is 1954
+NA_REAL = float(np.frombuffer(_NA_REAL_BYTES, dtype=">f8")[0])   # (the payload survives copies and byte swaps)
 R_3_3_3, R_2_3_0 = 0x00030303, 0x00020300
 
 _KIND = {LGLSXP: "lgl", INTSXP: "int", REALSXP: "real", STRSXP: "str", VECSXP: "list"}
@@ -62,8 +70,8 @@ class Pairlist(list):
 
 # ---------------------------------------------------------------------------------------------------- writer
 class _Writer:
-    def __init__(self, out: io.BytesIO):
-        self.out, self.symbols = out, {}
+    def __init__(self, out: io.BytesIO, nan_as_na: bool = False):
+        self.out, self.symbols, self.nan_as_na = out, {}, nan_as_na
 
     def i32(self, v: int):
         self.out.write(struct.pack(">i", v))
@@ -113,7 +121,14 @@ class _Writer:
             self.out.write(np.asarray(obj.values, dtype=">i4").tobytes())
         elif obj.kind == "real":
             v = np.asarray(obj.values, dtype=np.float64)
-            self.out.write(v.astype(">f8").tobytes())
+            if self.nan_as_na and np.isnan(v).any():
+                # a missing value of the host side (Python has no NA) is R's NA_real_, not an IEEE NaN: is.na() is
+                # TRUE for both, but R prints and summarises them differently
+                b = v.astype(">f8").view(">u8").copy()
+                b[np.isnan(v)] = np.frombuffer(_NA_REAL_BYTES, dtype=">u8")[0]
+                self.out.write(b.tobytes())
+            else:
+                self.out.write(v.astype(">f8").tobytes())
         elif obj.kind == "str":
             for s in obj.values:
                 self.charsxp(s)
@@ -124,14 +139,14 @@ class _Writer:
             self.pairlist(obj.attrs)
 
 
-def serialize(obj, rdata_names: Optional[List[str]] = None) -> bytes:
+def serialize(obj, rdata_names: Optional[List[str]] = None, nan_as_na: bool = False) -> bytes:
     """The uncompressed stream of `saveRDS(obj)`, or -- with rdata_names -- of `save(<names>)` where obj is the
-    list of the saved values."""
+    list of the saved values. nan_as_na: NaN entries of numeric vectors are written as R's NA_real_."""
     out = io.BytesIO()
     if rdata_names is not None:
         out.write(b"RDX2\n")
     out.write(b"X\n")
-    w = _Writer(out)
+    w = _Writer(out, nan_as_na)
     w.i32(2)
     w.i32(R_3_3_3)
     w.i32(R_2_3_0)
@@ -195,6 +210,8 @@ class _Reader:
                     raise ValueError("dotted pairlists are not supported")
         if t == CHARSXP:
             return self.charsxp(flags)
+        if t == ALTREP_SXP:
+            return self.altrep(flags)
         if t not in _KIND:
             raise ValueError(f"R object of type {t} is not supported (closures, environments, ... are not data)")
         n = self.i32()
@@ -214,12 +231,47 @@ class _Symbol(str):
     pass
 
 
+def _altrep(self, flags: int):
+    """An ALTREP item (serialisation version 3): info = pairlist(class symbol, package symbol, base type), state,
+    attributes. The classes base R uses for plain data are expanded into ordinary vectors."""
+    info, state, attrs = self.item(), self.item(), self.item()
+    cls = str(info[0][1]) if isinstance(info, Pairlist) and info else "?"
+    attrs = [(k, v) for k, v in (attrs or [])]
+    if cls in ("compact_intseq", "compact_realseq"):
+        n, start, step = (float(x) for x in state.values[:3])
+        seq = start + step * np.arange(int(n), dtype=np.float64)
+        if cls == "compact_intseq":
+            return RVec("int", seq.astype(np.int32), attrs)
+        return RVec("real", seq, attrs)
+    if cls.startswith("wrap_"):                       # state = list(x, metadata): the wrapped vector itself
+        inner = state.values[0] if isinstance(state, RVec) else state[0][1]
+        if isinstance(inner, RVec):
+            return RVec(inner.kind, inner.values, inner.attrs + attrs)
+        return inner
+    if cls == "deferred_string":                      # as.character(<integer or real vector>), not yet expanded
+        arg = state[0][1] if isinstance(state, Pairlist) else state
+        if isinstance(arg, RVec) and arg.kind == "int":
+            vals = [None if int(v) == NA_INT else str(int(v)) for v in arg.values]
+            return RVec("str", vals, attrs)
+        if isinstance(arg, RVec) and arg.kind == "real":
+            vals = [None if np.isnan(v) else (str(int(v)) if float(v).is_integer() and abs(v) < 1e15 else repr(float(v)))
+                    for v in arg.values]
+            return RVec("str", vals, attrs)
+    raise ValueError(f"ALTREP class '{cls}' is not supported by this reader: in R, re-save the object with "
+                     "save(..., version = 2), which expands it")
+
+
+_Reader.altrep = _altrep
+
+
 def unserialize(data: bytes):
     """Inverse of serialize(): returns the object of an .rds stream, or a Pairlist [(name, value), ...] for an
     .RData stream. Accepts gzip-compressed input."""
     if data[:2] == b"\x1f\x8b":
         data = gzip.decompress(data)
-    rdata = data[:5] == b"RDX2\n"
+    rdata = data[:5] in (b"RDX2\n", b"RDX3\n")      # save() of R < 3.5 (or version = 2) / of R >= 3.5
+    if data[:3] == b"RDA" or data[:3] == b"RDB":
+        raise ValueError("ASCII / native-binary .RData files are not supported: save(..., ascii = FALSE) writes XDR")
     if rdata:
         data = data[5:]
     if data[:2] != b"X\n":
@@ -307,10 +359,12 @@ def to_python(o):
     return a
 
 
-def save_rdata(path: str, objects: dict, compress: bool = True) -> None:
-    """`save(<names>, file = path)` for the objects of the dict (values: anything from_python accepts)."""
+def save_rdata(path: str, objects: dict, compress: bool = True, nan_as_na: bool = True) -> None:
+    """`save(<names>, file = path, version = 2)` for the objects of the dict (values: anything from_python accepts).
+    NaN in numeric vectors goes out as NA_real_ (the host side has no NA of its own: the `NA` entries R produces
+    through quirk Q6, R/bigKRLS.R:425-431 with which.derivatives, arrive here as NaN)."""
     names = list(objects.keys())
-    stream = serialize([from_python(objects[k]) for k in names], rdata_names=names)
+    stream = serialize([from_python(objects[k]) for k in names], rdata_names=names, nan_as_na=nan_as_na)
     with open(path, "wb") as f:
         f.write(gzip.compress(stream, mtime=0) if compress else stream)
 

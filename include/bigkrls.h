@@ -114,7 +114,12 @@ int bigkrls_temp_kernel(const double* A, int64_t u, const double* B, int64_t v, 
 
 /* replaces BigEigen(pA, Neig, pValBigMat, pVecBigMat) src/eigen.cpp:32-45
  * A symmetric n x n; vals[neig] descending; vecs n x neig (column k <-> vals[k]).
- * neig == n: full spectrum; neig < n: the neig algebraically largest pairs. */
+ * neig == n: full spectrum; neig < n: the neig ALGEBRAICALLY largest pairs.
+ * Difference from the reference for neig < n: arma::eigs_sym (src/eigen.cpp:21, default form "lm") returns the
+ * pairs of largest MAGNITUDE. The two agree on every positive semi-definite A -- a Gaussian kernel matrix, the only
+ * thing bigKRLS passes (R/bigKRLS.R:266) -- and whenever |most negative eigenvalue| < the neig-th largest one; an
+ * indefinite A whose negative end dominates gets different pairs here. A caller that needs "lm" on such a matrix
+ * can call this on A and on -A and merge. */
 int bigkrls_eigen(const double* A, int64_t n, int64_t neig, double* vals, double* vecs);
 
 /* replaces BigSolveForc(pEigenvectors, Eigenvalues, y, lambda)  src/solveforc.cpp:67-78

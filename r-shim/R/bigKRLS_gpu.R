@@ -8,7 +8,8 @@
 #
 # R is not installed in the build image: this file is written, not run, there. bigkrls_amd/api.py is the same
 # wrapper in Python and is what the parity tests drive; tests/test_rshim_cpu.py checks that every shim routine
-# called here exists in bigkrls_shim.cpp with the same number of arguments.
+# called here exists in bigkrls_shim.cpp with the same number of arguments. summary.bigKRLS(),
+# crossvalidate.bigKRLS() and summary.bigKRLS_CV() are in bigKRLS_gpu_methods.R.
 
 .bigkrls <- new.env()
 
@@ -156,12 +157,21 @@ predict.bigKRLS <- function(object, newdata, se.pred = FALSE, correct_SE = TRUE,
     }
   }
   neff <- if (correct_SE && !is.null(object$Neffective)) object$Neffective else 0
+  u <- nrow(nd); n <- nrow(Xh)
+  newdataK <- dev_matrix(ctx, u, n)                                # R/bigKRLS.R:604, returned at :629
+  vcov.est.pred <- if (se.pred) dev_matrix(ctx, u, u) else NULL    # :608, returned at :628
   out <- BigKRLSPredict(ctx, Xh, as.double(object$y), as.double(object$coeffs), object$sigma, nd,
-                        if (se.pred) Vc$ptr else NULL, neff, se.pred)
+                        if (se.pred) Vc$ptr else NULL, neff, se.pred, newdataK$ptr,
+                        if (se.pred) vcov.est.pred$ptr else NULL)
+  bigmatrix.in <- is.dev_matrix(newdata) || object$has.big.matrices
+  if (!bigmatrix.in) {                                             # :623-626: base R matrices unless big ones came in
+    newdataK <- newdataK[]
+    if (se.pred) vcov.est.pred <- vcov.est.pred[]
+  }
   res <- list(predicted = matrix(out$predicted, ncol = 1),
               se.pred = if (se.pred) matrix(out$se.pred, ncol = 1) else NULL,
-              vcov.est.pred = NULL, newdata = newdata, newdataK = NULL,
-              has.big.matrices = is.dev_matrix(newdata) || object$has.big.matrices, ytest = ytest)
+              vcov.est.pred = vcov.est.pred, newdata = newdata, newdataK = newdataK,
+              has.big.matrices = bigmatrix.in, ytest = ytest)
   class(res) <- "bigKRLS_predicted"
   res
 }
@@ -181,7 +191,9 @@ save.bigKRLS <- function(object, model_subfolder_name, overwrite.existing = FALS
   }
   bigKRLS_out <- object[!big]
   class(bigKRLS_out) <- class(object)
-  save(bigKRLS_out, file = file.path(folder, "estimates.RData"))
+  # version = 2: the serialisation format every R since 2.3.0 reads and the one bigkrls_amd/rdata.py writes; its
+  # reader also takes the version-3 files a plain save() of R >= 3.5 produces
+  save(bigKRLS_out, file = file.path(folder, "estimates.RData"), version = 2)
   invisible(folder)
 }
 

@@ -56,6 +56,15 @@ def worker():
     trunc = float(sys.argv[sys.argv.index("--eigtrunc") + 1]) if "--eigtrunc" in sys.argv else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     fault_rank = int(sys.argv[sys.argv.index("--fault-rank") + 1]) if "--fault-rank" in sys.argv else None
+    watchdog_rank = int(sys.argv[sys.argv.index("--watchdog-rank") + 1]) if "--watchdog-rank" in sys.argv else None
+    if watchdog_rank is not None:
+        # the test build again: ONE rank reports a fired persistent-kernel watchdog after the distributed stage 1; all
+        # ranks must agree on it, replay the decomposition with the per-step kernels and finish with the right answer
+        import bigkrls_amd._lib as L
+        L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "libbigkrls_hip_fault.so")
+        if rank == watchdog_rank:
+            os.environ["BIGKRLS_FAULT"] = "watchdog"
+        os.environ["BIGKRLS_VERBOSE"] = "1"
     if fault_rank is not None:
         # the test build of the library (fault-injection hooks compiled in); the fault itself only in ONE rank's process
         import bigkrls_amd._lib as L

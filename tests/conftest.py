@@ -22,6 +22,8 @@ WORLD_CASES = {
     "dense_world3_binary_which": ["1200", "5", "3", "--eigtrunc", "0.01", "--options"],
     # a local failure in ONE rank (test build of the library): every rank must return the error, none may hang
     "dense_world2_rank_failure": ["600", "4", "2", "--eigtrunc", "0.001", "--fault-rank", "1"],                # n <= 256: K gathered, Q by all-reduce
+    # ONE rank's persistent-kernel watchdog fires (test build): agreed on by all ranks, decomposition replayed everywhere
+    "dense_world2_watchdog_replay": ["900", "4", "2", "--eigtrunc", "0.001", "--watchdog-rank", "1"],
 }
 _world_runs = {}
 

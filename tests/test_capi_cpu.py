@@ -3,6 +3,8 @@ symbol include/bigkrls.h declares, and fails loudly (no CPU fallback) without a 
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -157,3 +159,23 @@ def test_plain_c_caller_builds_and_fails_loudly_without_gpu():
     coeffs, res = np.zeros(40), np.zeros(8)
     st = ex.capi_fit_example(X.ctypes.data, y.ctypes.data, 40, 3, 5, coeffs.ctypes.data, res.ctypes.data)
     assert st == _lib.ENODEVICE and not coeffs.any() and not res.any()
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """include/bigkrls.h: without librccl, bigkrls_comm_unique_id / bigkrls_comm_create return BIGKRLS_ENODEVICE with
+    a message (the not-found branch used to call dlerror() twice and pass its second, NULL, result to std::string).
+    A fresh process: the loader's choice is made once per process."""
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from bigkrls_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "uid = C.create_string_buffer(128)\n"
+        "st = lib.bigkrls_comm_unique_id(uid)\n"
+        "msg = lib.bigkrls_last_error().decode()\n"
+        "assert st == _lib.ENODEVICE, st\n"
+        "assert 'librccl not found' in msg and 'no_such_rccl' in msg, msg\n"
+        "print('OK')\n")
+    env = dict(os.environ, BIGKRLS_RCCL_LIB="/nonexistent/no_such_rccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

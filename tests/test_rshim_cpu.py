@@ -1,17 +1,21 @@
 """The R-side boundary artefacts (r-shim/) against the C ABI they bind (include/bigkrls.h).
 
-R and Rcpp are absent from the image, so the shim cannot be compiled here; what can be checked is that it
-stays in step with the header: every bigkrls_* call in r-shim/src/bigkrls_shim.cpp names a declared function
+R and Rcpp are absent from the image, so the shim cannot be built into the R package here. What is checked: the shim
+is TYPE-CHECKED by g++ (-fsyntax-only -Wall -Werror) against include/bigkrls.h and a minimal mock of the Rcpp /
+bigmemory declarations it uses (tests/rshim_mock/), and it stays in step with the header: every bigkrls_* call in r-shim/src/bigkrls_shim.cpp names a declared function
 and passes as many arguments as its prototype takes, the eleven .Call routines of the reference
 (src/RcppExports.cpp:147-160) are all exported with the reference's arities, and every shim routine the R
 host functions (r-shim/R/bigKRLS_gpu.R) call exists with that many parameters."""
 import os
 import re
+import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "bigkrls.h")
 SHIM = os.path.join(ROOT, "r-shim", "src", "bigkrls_shim.cpp")
 RHOST = os.path.join(ROOT, "r-shim", "R", "bigKRLS_gpu.R")
+RMETHODS = os.path.join(ROOT, "r-shim", "R", "bigKRLS_gpu_methods.R")
+MOCK = os.path.join(ROOT, "tests", "rshim_mock")
 
 # .Call routines registered by the reference and their arities (src/RcppExports.cpp:147-160)
 REFERENCE_CALLS = {"BigNeffective": 1, "BigDerivMat": 7, "BigCrossProd": 3, "BigXtX": 2, "BigTCrossProd": 3,
@@ -118,14 +122,14 @@ def test_the_reference_call_routines_are_all_exported_with_their_arities():
 
 def test_r_host_functions_call_existing_shim_routines():
     exports = _shim_exports()
-    rsrc = _strip_comments(open(RHOST).read().replace("//", "  "), hash_comments=True)
+    rsrc = _strip_comments((open(RHOST).read() + "\n" + open(RMETHODS).read()).replace("//", "  "), hash_comments=True)
     level2 = [n for n in exports if n not in REFERENCE_CALLS]
     assert {"DevContext", "DevMatrix", "DevToHost", "HostToDev", "BigKRLSFit", "BigKRLSPredict"} <= set(level2)
     seen = set()
     for name, args in _calls(rsrc, r"\b(" + "|".join(level2) + r")"):
         assert len(args) == exports[name], f"{name}: R passes {len(args)} arguments, the shim takes {exports[name]}"
         seen.add(name)
-    assert {"DevContext", "DevMatrix", "DevToHost", "BigKRLSFit", "BigKRLSPredict"} <= seen
+    assert {"DevContext", "DevMatrix", "DevToHost", "BigKRLSFit", "BigKRLSPredict", "NeffectiveHost"} <= seen
     # balanced brackets: the file cannot be parsed by R here, at least it is not truncated or mis-nested
     stack = []
     for ch in re.sub(r"\"[^\"\n]*\"|'[^'\n]*'", "", rsrc):
@@ -140,3 +144,64 @@ def test_r_host_functions_call_existing_shim_routines():
     assert names[:18] == ["y", "X", "sigma", "derivative", "which.derivatives", "vcov.est", "Neig", "eigtrunc",
                           "lambda", "L", "U", "tol", "model_subfolder_name", "overwrite.existing", "Ncores", "acf",
                           "noisy", "instructions"]
+
+
+def _syntax_check(path, extra=()):
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
+           "-I" + os.path.join(ROOT, "include"), "-I" + MOCK, *extra, path]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+
+
+def test_shim_type_checks_against_the_header_and_the_rcpp_mock(tmp_path):
+    r = _syntax_check(SHIM)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # the check has teeth: a call with a wrong argument type, and `delete` of an opaque handle, are both rejected
+    bad = tmp_path / "bad.cpp"
+    bad.write_text('#include <Rcpp.h>\n#include "bigkrls.h"\n'
+                   "void f(SEXP c, Rcpp::NumericMatrix X) { bigkrls_ctx* p = nullptr; bigkrls_ctx_create(X, &p); }\n")
+    assert _syntax_check(str(bad)).returncode != 0
+    bad.write_text('#include <Rcpp.h>\n#include "bigkrls.h"\nvoid f(bigkrls_ctx* p) { delete p; }\n')
+    assert _syntax_check(str(bad)).returncode != 0
+    # no XPtr over an opaque ABI type (its default finaliser would delete an incomplete type), and every handle the
+    # shim creates is released by the ABI's own function through a registered finaliser
+    src = _strip_comments(open(SHIM).read())
+    assert not re.search(r"XPtr<\s*bigkrls_", src)
+    for fin, release in (("ctx_finalizer", "bigkrls_ctx_destroy"), ("comm_finalizer", "bigkrls_comm_destroy"),
+                         ("dev_finalizer", "bigkrls_dev_free")):
+        body = re.search(r"static void " + fin + r"\(SEXP s\) \{(.*?)\n\}", src, flags=re.S)
+        assert body and release in body.group(1), fin
+        assert re.search(r"R_RegisterCFinalizerEx\(s, " + fin, src), fin
+
+
+def test_r_methods_keep_the_reference_signatures_and_fields():
+    """summary.bigKRLS (R/bigKRLS.R:706-707), crossvalidate.bigKRLS (:1146), summary.bigKRLS_CV (:760) and what
+    predict.bigKRLS returns (:628-631)."""
+    msrc = open(RMETHODS).read()
+
+    def signature(name):
+        m = re.search(re.escape(name) + r" <- function\((.*?)\)\s*\{", msrc, flags=re.S)
+        assert m, name
+        return [a.split("=")[0].strip() for a in _split_args(m.group(1))]
+
+    assert signature("summary.bigKRLS") == ["object", "degrees", "probs", "digits", "labs", "..."]
+    assert signature("crossvalidate.bigKRLS")[:6] == ["y", "X", "seed", "Kfolds", "ptesting", "estimates_subfolder"]
+    assert signature("crossvalidate.bigKRLS")[-1] == "..."
+    assert signature("summary.bigKRLS_CV") == ["object", "..."]
+    for field in ("R2_is", "R2_oos", "MSE_is", "MSE_oos", "R2AME_is", "R2AME_oos", "MSE_AME_is", "MSE_AME_oos",
+                  "pseudoR2_is", "pseudoR2_oos", "pseudoR2AME_is", "pseudoR2AME_oos", "ptesting", "indices", "folds",
+                  "Kfolds", "seed", "ttests", "percentiles"):
+        assert field in msrc, field
+    hsrc = open(RHOST).read()
+    pred = hsrc[hsrc.index("predict.bigKRLS <- function"):hsrc.index("# ---- save / load")]
+    for field in ("predicted", "se.pred", "vcov.est.pred", "newdata", "newdataK", "has.big.matrices", "ytest"):
+        assert re.search(r"\b" + re.escape(field) + r"\s*=", pred), field
+    assert "vcov.est.pred = NULL" not in pred and "newdataK = NULL" not in pred
+    assert 'version = 2' in hsrc                      # files every R reads, and the format rdata.py writes
+    # brackets of the methods file balance (R cannot parse it here)
+    stack = []
+    for ch in re.sub(r"\"[^\"\n]*\"|'[^'\n]*'", "", _strip_comments(msrc.replace("//", "  "), hash_comments=True)):
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in ")]}":
+            assert stack and "([{".index(stack.pop()) == ")]}".index(ch)
+    assert not stack
