@@ -266,7 +266,14 @@ def bigKRLS(y=None, X=None, sigma=None, derivative=True, which_derivatives=None,
     w["_ctx"] = ctx
     if model_subfolder_name is not None:                                          # :471-504
         from .persist import save_bigKRLS
-        save_bigKRLS(w, model_subfolder_name, overwrite_existing=overwrite_existing, noisy=noisy)
+        if comm is None:
+            save_bigKRLS(w, model_subfolder_name, overwrite_existing=overwrite_existing, noisy=noisy)
+        elif comm.rank == 0:
+            # every rank holds the same small outputs: ONE rank writes them (several would race for the folder name);
+            # the sharded column blocks are not members load_bigKRLS knows and stay on the GPUs
+            small = BigKRLS({k: v for k, v in w.items() if not k.endswith(".cols")})
+            save_bigKRLS(small, model_subfolder_name, overwrite_existing=overwrite_existing, noisy=noisy)
+            w["path"], w["model_subfolder_name"] = small["path"], small["model_subfolder_name"]
     return w
 
 

@@ -120,9 +120,19 @@ int comm_broadcast(bigkrls_comm* comm, double* dbuf, int64_t count, int root) {
   return BIGKRLS_OK;
 }
 
+// the device word(s) and the pinned scratch the status agreement goes through: allocated when the communicator is
+// created, so that a rank short of memory later can still take part in comm_agree
+static int comm_prealloc(bigkrls_ctx* ctx) {
+  void* p = nullptr;
+  double* hp = nullptr;
+  BK_TRY(ws_get(ctx, SLOT_COMM_SMALL, 64 * sizeof(double), &p));
+  return pinned_get(ctx, 64, &hp);
+}
+
 int comm_all_reduce_host(bigkrls_comm* comm, double* h_vals, int64_t count, int op) {
   if (!comm || count <= 0) return BIGKRLS_OK;
   bigkrls_ctx* ctx = comm->ctx;
+  BK_REQUIRE(ctx, "this communicator was created without a device context: it can only be passed to bigkrls_comm_check");
   void* p = nullptr;
   BK_TRY(ws_get(ctx, SLOT_COMM_SMALL, std::max<int64_t>(count, 64) * sizeof(double), &p));
   double* hp = nullptr;
@@ -325,6 +335,7 @@ int bigkrls_comm_create(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const vo
   BK_HIP(hipSetDevice(ctx->device));
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof id);
+  BK_TRY(comm_prealloc(ctx));
   ncclComm_t c = nullptr;
   BK_NCCL(rccl().CommInitRank(&c, nranks, id, rank));
   bigkrls_comm* comm = new bigkrls_comm();
@@ -342,6 +353,7 @@ int bigkrls_comm_create_callbacks(bigkrls_ctx* ctx, int32_t nranks, int32_t rank
   BK_REQUIRE(table->struct_bytes == (int64_t)sizeof(bigkrls_collectives), "comm_create_callbacks: table struct size mismatch");
   BK_REQUIRE(table->all_reduce && table->all_gather && table->broadcast, "comm_create_callbacks: a callback is missing");
   BK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_create_callbacks: bad rank / nranks");
+  if (ctx) BK_TRY(comm_prealloc(ctx));
   bigkrls_comm* comm = new bigkrls_comm();
   comm->ctx = ctx;
   comm->nranks = nranks;

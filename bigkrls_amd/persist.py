@@ -13,9 +13,15 @@ matrices named in bLoad (:336-343) that exist as text files. Here:
     to `<member>.npy` (column-major float64), because an N x N text dump is what dominates the
     reference's save time at large N (SURVEY 8f);
   * the base-R part goes to `estimates.RData` in R's own serialisation format (bigkrls_amd/rdata.py: XDR
-    version 2, gzip, one pairlist entry named `bigKRLS_out` / `object` with its class attribute), so a folder
-    written here is one R's load.bigKRLS() can open and vice versa. R is absent from the image: the format is
-    pinned by the one R-written file of the reference tree (tests/test_rdata.py), not by an R session.
+    version 2, gzip, one pairlist entry named `bigKRLS_out` / `object` with its class attribute): version 2 is what
+    every R since 2.3.0 loads, so a folder written here is one R's load.bigKRLS() can open. The other direction: the
+    reader takes version-2 files (R < 3.5, `save(..., version = 2)` -- what the r-shim's save.bigKRLS writes) and
+    the version-3 / `RDX3` files of a plain `save()` under R >= 3.5, with the ALTREP classes base R uses for plain
+    data expanded (compact sequences, wrap_*, deferred strings; any other ALTREP class is refused by name). R is
+    absent from the image: version 2 is pinned by the one R-written file of the reference tree
+    (tests/test_rdata.py), version 3 only by hand-assembled streams, neither by an R session.
+  * a fit that ran over several ranks (`comm=`) is saved by rank 0 only, without the N x N matrices: they stay
+    sharded on the GPUs (`K.cols`, ...), and load.bigKRLS has no member to load them into.
 """
 from __future__ import annotations
 
