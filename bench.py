@@ -128,9 +128,9 @@ class CpuBaseline:
     done or the budget is spent (then the child, this exact PID, is killed) and assembles the
     `cpu_baseline` object from the phases measured until then."""
 
-    def __init__(self, n, p, seed, eigtrunc, small_n=2000):
+    def __init__(self, n, p, seed, eigtrunc, small_n=2000, budget_s=900.0):
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--p", str(p),
-               "--seed", str(seed), "--small-n", str(small_n)]
+               "--seed", str(seed), "--small-n", str(small_n), "--budget-s", str(budget_s)]
         if eigtrunc is not None:
             cmd += ["--eigtrunc", str(eigtrunc)]
         self.n, self.p = n, p
@@ -178,20 +178,23 @@ class CpuBaseline:
         if "done" in ph:
             d = ph["done"]
             ex = [k for k in lit_keys if ph.get(k, {}).get("extrapolated")]
-            ex_s = sum(ph[k]["s"] for k in ex)
+            # seconds of `value` that were scaled from timed samples rather than timed (the child reports them per phase)
+            ex_s = sum(ph[k].get("extrapolated_s", ph[k]["s"]) for k in ex)
+            lam_ph, der_ph = ph.get("lambda", {}), ph.get("derivatives", {})
             res.update({
                 "value": d["literal_s"],
-                "extrapolated": True,
+                "extrapolated": bool(ex),
                 "efficient_port_s": d["efficient_s"],
                 "sample": (f"literal restatement of the reference at the bench size N={self.n}, P={self.p} "
                            f"(BLAS/LAPACK threads = {cores}: the thread cap of numpy/scipy's bundled OpenBLAS on this "
-                           f"{host_cpus}-CPU host; hand loops single-threaded like the reference): kernel "
-                           "row loop, dsyevd and V in full; lambda search = one literal solveforc probe x "
-                           f"{d['probes']} probes; V_yhat (4N^3) and one derivative column's L'VL (4N^3) on N/20 "
-                           f"columns x 20, the column then x P={self.p} (all three marked extrapolated: "
-                           f"{ex_s:.0f} s = {100.0 * ex_s / max(d['literal_s'], 1e-9):.0f} % of `value` is scaled from "
-                           "samples, efficient_port_s is measured in full); "
-                           f"efficient_port_s = the O(N^2 K) identities in full at N={self.n}"),
+                           f"{host_cpus}-CPU host; hand loops single-threaded like the reference), timed IN FULL: kernel "
+                           "row loop, dsyevd, V, V_yhat = crossprod(K, V K) (4N^3), "
+                           f"{lam_ph.get('probes_timed', 1)} of the {d['probes']} literal solveforc probes of the lambda "
+                           f"search and {der_ph.get('columns_timed', 1)} of the P={self.p} literal derivative columns "
+                           "(each with its 4N^3 term L'VL), as many as the --cpu-budget-s allowed; the untimed probes and "
+                           f"columns enter at the mean of the timed ones: {ex_s:.0f} s = "
+                           f"{100.0 * ex_s / max(d['literal_s'], 1e-9):.0f} % of `value` is scaled, the rest and "
+                           f"efficient_port_s (the O(N^2 K) identities at N={self.n}) are measured in full"),
                 "phases_s": {k: ph[k]["s"] for k in lit_keys if k in ph},
                 "extrapolated_phases": ex, "extrapolated_share": round(ex_s / max(d["literal_s"], 1e-9), 3),
                 "host_cpus": int(host_cpus),
@@ -352,7 +355,7 @@ def main():
     cpu = None
     cpu_n = args.cpu_n if args.cpu_n is not None else (cfg["n"] if cfg["n"] <= 20000 else None)
     if world == 1 and rank == 0 and not args.no_cpu_baseline and cpu_n is not None:
-        cpu = CpuBaseline(cpu_n, cfg["p"], cfg["seed"], cfg["eigtrunc"])
+        cpu = CpuBaseline(cpu_n, cfg["p"], cfg["seed"], cfg["eigtrunc"], budget_s=args.cpu_budget_s)
 
     import numpy as np
     import torch

@@ -10,14 +10,16 @@ scipy's OpenBLAS, hand loops single-threaded like the reference -- at the bench 
 phase:
   kernel       src/gauss_kernel.cpp:13-30 row loop, in full
   eigen        src/eigen.cpp:24 eig_sym == dsyevd of the N x N kernel, in full
-  lambda       src/solveforc.cpp:36-53 row loop: ONE literal probe timed, times the number of probes
-               of the golden-section search (R/bigKRLS_Rcpp_functions.R:38-77)           [extrapolated]
+  lambda       src/solveforc.cpp:36-53 row loop: --probes literal probes timed in full (default 6, at lambdas the
+               golden-section search really visits), their mean times the number of probes of the search
+               (R/bigKRLS_Rcpp_functions.R:38-77)                      [the untimed probes are extrapolated]
   coeffs       one more literal solveforc + K %*% c
   vcov_c       V = (Q diag) Q' (R/bigKRLS.R:299-301), in full
-  vcov_fitted  crossprod(K, V %*% K) (R/bigKRLS.R:307, 4 N^3): a column block of N/frac columns
-               through both products, times frac                                        [extrapolated]
-  derivatives  src/bigderiv_v3.cpp:90-106 for ONE column: L = (x_r - x_i) o K and L c in full,
-               sum(L' V L) on a column block of N/frac columns times frac, then times P  [extrapolated]
+  vcov_fitted  crossprod(K, V %*% K) (R/bigKRLS.R:307, 4 N^3), in full
+  derivatives  src/bigderiv_v3.cpp:90-106 per column: L = (x_r - x_i) o K, L c and sum(L' V L) (4 N^3) IN FULL for as
+               many columns as the time budget allows (--budget-s, at least one), their mean times P
+                                                                      [the untimed columns are extrapolated]
+Every phase line carries `extrapolated_s`, the part of its seconds that was scaled rather than timed.
 and the efficient port (the O(N^2 K) identities the HIP path uses, oracle `*_fast`) in full at the same N,
 sharing the kernel and eigen measurements. The full literal fit at N=2000 is kept as a second sample.
 
@@ -47,7 +49,9 @@ def main():
     ap.add_argument("--seed", type=int, default=103)
     ap.add_argument("--eigtrunc", type=float, default=None)
     ap.add_argument("--small-n", type=int, default=2000)
-    ap.add_argument("--frac", type=int, default=20, help="the N^3 products run on N/frac columns")
+    ap.add_argument("--probes", type=int, default=6, help="literal solveforc probes timed in full")
+    ap.add_argument("--budget-s", type=float, default=900.0,
+                    help="wall-clock the parent allows: literal derivative columns are timed in full while they fit")
     ap.add_argument("--no-wait", action="store_true")
     args = ap.parse_args()
 
@@ -65,6 +69,7 @@ def main():
     emit(phase="ready", cores=int(threads), cpu_count=os.cpu_count())
     if not args.no_wait:
         sys.stdin.readline()                       # the parent's "go"
+    t_start = time.perf_counter()
 
     n, p = args.n, args.p
     # ---- second sample: the complete literal fit at small N ------------------------------------
@@ -113,17 +118,22 @@ def main():
     emit(phase="efficient_lambda_coeffs", lambda_s=round(t_lambda_fast, 3), coeffs_s=round(t_coeffs_fast, 3),
          probes=nprobes, lam=lam)
 
-    # ---- literal lambda search: one probe of the row loop, times the number of probes -----------
-    t0 = time.perf_counter()
-    le_l, c_l = orc.solveforc_literal(Q, vals, ys, lam)
-    t_probe = time.perf_counter() - t0
-    assert abs(le_l - le) <= 1e-8 * abs(le)
+    # ---- literal lambda search: --probes probes of the row loop in full, the rest at their mean ------------------
+    lams = [float(pr[0]) for pr in tr.probes][:max(0, args.probes - 1)] + [lam]   # lambdas the search visited + the final one
+    t_probes = []
+    for lv in lams[-max(1, args.probes):]:
+        t0 = time.perf_counter()
+        le_l, c_l = orc.solveforc_literal(Q, vals, ys, lv)
+        t_probes.append(time.perf_counter() - t0)
+    assert abs(le_l - le) <= 1e-8 * abs(le)                                 # (the last one ran at the final lambda)
+    t_probe = sum(t_probes) / len(t_probes)
+    n_timed = min(len(t_probes), nprobes)
     emit(phase="lambda", s=round(t_probe * nprobes, 3), one_probe_s=round(t_probe, 3), probes=nprobes,
-         extrapolated=True)
+         probes_timed=n_timed, extrapolated=n_timed < nprobes, extrapolated_s=round(t_probe * (nprobes - n_timed), 3))
     t0 = time.perf_counter()
     _ = K @ c_l
     t_coeffs = t_probe + (time.perf_counter() - t0)
-    emit(phase="coeffs", s=round(t_coeffs, 3), extrapolated=False)
+    emit(phase="coeffs", s=round(t_coeffs, 3), extrapolated=False, extrapolated_s=0.0)
 
     # ---- variance matrices ------------------------------------------------------------------------
     resid = ys - yfit
@@ -132,38 +142,41 @@ def main():
     t0 = time.perf_counter()
     V = orc.tcrossprod(orc.multdiag(Q, sigmasq * (vals + lam) ** -2.0), Q)
     t_vc = time.perf_counter() - t0
-    emit(phase="vcov_c", s=round(t_vc, 3), extrapolated=False)
-    nc = max(1, n // args.frac)
-    scale = n / nc
+    emit(phase="vcov_c", s=round(t_vc, 3), extrapolated=False, extrapolated_s=0.0)
     t0 = time.perf_counter()
-    VK = V @ K[:, :nc]
-    _ = K.T @ VK                                    # crossprod(K, V %*% K), R/bigKRLS.R:307
-    t_vf = (time.perf_counter() - t0) * scale
+    VK = V @ K
+    _ = K.T @ VK                                    # crossprod(K, V %*% K), R/bigKRLS.R:307, in full
+    t_vf = time.perf_counter() - t0
     del VK, _
-    emit(phase="vcov_fitted", s=round(t_vf, 3), columns=nc, extrapolated=True)
+    emit(phase="vcov_fitted", s=round(t_vf, 3), extrapolated=False, extrapolated_s=0.0)
     t0 = time.perf_counter()
     dd = vals[:k]
     Vyhat = (Q * (wv * dd * dd)) @ Q.T
     t_vf_fast = time.perf_counter() - t0
     del Vyhat
 
-    # ---- one derivative column, literal (src/bigderiv_v3.cpp:90-106) ------------------------------
-    xj = Xs[:, 0]
-    t0 = time.perf_counter()
-    Lm = (xj[:, None] - xj[None, :]) * K            # :95, :102
-    dcol = (-2.0 / sigma) * (Lm @ c)                # :103
-    t_full = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    VL = V @ Lm[:, :nc]
-    _ = float(np.sum(Lm.T @ VL))                    # :105 on a column block
-    t_cube = (time.perf_counter() - t0) * scale
-    del VL, Lm
-    t_dcol = t_full + t_cube
-    emit(phase="derivatives", s=round(t_dcol * p, 3), one_column_s=round(t_dcol, 3), columns=nc, extrapolated=True)
+    # ---- derivative columns, literal and in full (src/bigderiv_v3.cpp:90-106), while the budget allows -------------
+    t_cols, dcol0 = [], None
+    for j in range(p):
+        if j > 0 and (time.perf_counter() - t_start) + 1.25 * max(t_cols) + 45.0 > args.budget_s:
+            break                                   # (45 s: the efficient port's derivatives + exit)
+        xj = Xs[:, j]
+        t0 = time.perf_counter()
+        Lm = (xj[:, None] - xj[None, :]) * K        # :95, :102
+        dcol = (-2.0 / sigma) * (Lm @ c)            # :103
+        VL = V @ Lm
+        _ = float(np.sum(Lm.T @ VL))                # :105, the 4 N^3 term, in full
+        t_cols.append(time.perf_counter() - t0)
+        del VL, Lm
+        if j == 0:
+            dcol0 = dcol
+    t_dcol = sum(t_cols) / len(t_cols)
+    emit(phase="derivatives", s=round(t_dcol * p, 3), one_column_s=round(t_dcol, 3), columns_timed=len(t_cols),
+         extrapolated=len(t_cols) < p, extrapolated_s=round(t_dcol * (p - len(t_cols)), 3))
     t0 = time.perf_counter()
     D, var = orc.derivmat_fast(Xs, K, c, sigma, Q, wv)
     t_deriv_fast = time.perf_counter() - t0
-    assert np.max(np.abs(D[:, 0] - dcol)) <= 1e-9 * np.max(np.abs(dcol))
+    assert np.max(np.abs(D[:, 0] - dcol0)) <= 1e-9 * np.max(np.abs(dcol0))
 
     literal = t_kernel + t_eigen + t_probe * nprobes + t_coeffs + t_vc + t_vf + t_dcol * p
     efficient = t_kernel + t_eigen + t_lambda_fast + t_coeffs_fast + t_vc + t_vf_fast + t_deriv_fast

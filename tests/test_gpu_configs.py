@@ -94,6 +94,42 @@ def derivative_identities(ctx, ops, out, K, Xs, cols, sigma):
         assert rel(D[:, i], (-2.0 / sigma) * (x * Kc - Kxc)) < 1e-9, j
 
 
+def host_checks_from_downloaded_pairs(ctx, ops, out, K, Qh, Xs, ys, X, y, cols, rows, dvc, dvf, sigma):
+    """Checks whose expected values contain NOTHING computed by the library but (i) the eigenpairs of the fit,
+    downloaded (their residual against K is checked separately), and (ii) a few rows of K, downloaded and pinned
+    against the literal kernel formula here: lambda, Le and c from the oracle's golden-section search and solveforc
+    on the host (R/bigKRLS_Rcpp_functions.R:5-82, src/solveforc.cpp:13-65); the derivatives of `cols` at `rows`
+    from numpy products with the K rows (src/bigderiv_v3.cpp:103); the diagonals of both variance matrices from the
+    host copy of Q (R/bigKRLS.R:299-307, :438, :445). `dvc`, `dvf`: the diagonals as the fit returned them."""
+    n = Xs.shape[0]
+    d = out["K.eigenvalues"]
+    k = out["lastkeeper"]
+    eig_h = orc.EigenObject(values=d, lastkeeper=k, vectors=Qh[:, :k])
+    lam_h = orc.lambda_search(eig_h, ys)
+    assert abs(out["lambda"] - lam_h) <= TOL * lam_h
+    le_h, c_h = orc.solveforc_fast(eig_h.vectors, eig_h.values, ys, lam_h)
+    assert rel(out["coeffs"], c_h) < TOL
+    assert abs(out["Le"] - le_h) <= TOL * le_h
+    # K rows: pulled from the device, checked entry by entry against exp(-||x_i - x_j||^2 / sigma)
+    Krows = ops.gemm(False, False, K, ctx.from_numpy(unit_columns(n, rows))).to_numpy().T     # len(rows) x n
+    for a, r in enumerate(rows):
+        assert rel(Krows[a], orc.temp_kernel_literal(Xs, Xs[r:r + 1], sigma).ravel()) < 1e-13, r
+    assert rel(out["yfitted.std"][rows], Krows @ c_h) < TOL                                   # R/bigKRLS.R:291
+    which = out["which.derivatives"]
+    for j in cols:
+        i = j if which is None else which.index(j + 1)
+        x = Xs[:, j]
+        want = (-2.0 / sigma) * (x[rows] * (Krows @ c_h) - Krows @ (x * c_h))                 # src/bigderiv_v3.cpp:103
+        assert rel(out["derivatives.std"][rows, i], want) < TOL, j
+    sigsq_h = out["sigmasq"]
+    wv = sigsq_h * (d[:k] + lam_h) ** -2.0
+    sd2 = y.std(ddof=1) ** 2
+    q2 = Qh[:, :k] ** 2
+    assert rel(dvc, sd2 * (q2 @ wv)) < TOL
+    assert rel(dvf, sd2 * (q2 @ (wv * d[:k] ** 2))) < TOL
+    return lam_h, c_h
+
+
 # --------------------------------------------------------------------------------------------
 # C2
 # --------------------------------------------------------------------------------------------
@@ -315,6 +351,13 @@ def test_c4_fit_properties_and_lanczos_vs_dense(ctx, monkeypatch):
     q2 = Qh[:, :k] ** 2
     assert rel(out["vcov.est.c"].diag().ravel(), sd2 * (q2 @ wv)) < TOL
     assert rel(out["vcov.est.fitted"].diag().ravel(), sd2 * (q2 @ (wv * d[:k] ** 2))) < TOL
+    # lambda, Le and c from the oracle's search / solveforc on the HOST, fed with the downloaded pairs
+    # (the C3 pattern minus ARPACK: nothing of the library's own matvec in the expected values)
+    t0 = time.perf_counter()
+    lam_h, _ = host_checks_from_downloaded_pairs(ctx, ops, out, K, Qh, Xs, ys, X, y, [0, 11, 19],
+                                                 np.array([3, 25000, n - 2]), out["vcov.est.c"].diag().ravel(),
+                                                 out["vcov.est.fitted"].diag().ravel(), float(p))
+    print(f"C4: host lambda search / solveforc / K rows in {time.perf_counter() - t0:.1f} s, lambda {lam_h:.12g}")
     del Qh, q2
     tv = out["vcov.est.c"].diag().sum() / sd2
     tf = out["vcov.est.fitted"].diag().sum() / sd2
@@ -372,6 +415,8 @@ def test_c5_fit_properties_which_derivatives(ctx, monkeypatch):
     tf = out["vcov.est.fitted"].diag().sum() / sd2
     assert abs(tv - out["sigmasq"] * np.sum((d[:k] + lam) ** -2.0)) < 1e-8 * tv
     assert abs(tf - out["sigmasq"] * np.sum(d[:k] ** 2 * (d[:k] + lam) ** -2.0)) < 1e-8 * tf
+    dvc = out["vcov.est.c"].diag().ravel()
+    dvf = out["vcov.est.fitted"].diag().ravel()
     out["vcov.est.c"] = out["vcov.est.fitted"] = None           # 160 GB back to the allocator
     ctx.torch.cuda.empty_cache()
     K = out["K"]
@@ -393,6 +438,15 @@ def test_c5_fit_properties_which_derivatives(ctx, monkeypatch):
         qs = ops.matvec(eo.vectors, ctx.from_numpy(s), trans=True).to_numpy().ravel()
         want = 4.0 / (float(p) ** 2 * float(n) ** 2) * float(np.sum(wv * qs * qs))
         assert abs(out["var.avgderivatives.std"][i] - want) <= 1e-8 * want
+    # the host-side sample C4 has: three K rows against the literal formula, lambda / Le / c from the oracle on the
+    # host with the downloaded pairs, the three selected columns' derivatives at those rows from numpy products, the
+    # diagonals of both variance matrices from the host copy of Q -- independent of the library's own matvec
+    t0 = time.perf_counter()
+    Qh = eo.vectors.to_numpy()
+    lam_h, _ = host_checks_from_downloaded_pairs(ctx, ops, out, K, Qh, Xs, ys, X, y, cols,
+                                                 np.array([7, 50001, n - 3]), dvc, dvf, float(p))
+    print(f"C5: host lambda search / solveforc / K rows in {time.perf_counter() - t0:.1f} s, lambda {lam_h:.12g}")
+    del Qh
     # quirk Q6: rescaling by X.init.sd[1..3], not by the selected columns' sds
     sdx = X.std(0, ddof=1)
     sdy = y.std(ddof=1)
