@@ -520,7 +520,7 @@ int tridiagonalize(bigkrls_ctx* ctx, double* W, int n, double* d, double* e, dou
 struct MergeDesc {
   int s, n1, m, K;
   int k1, k2, k3, Kneed;
-  int rot_off, nrot, ndef, pad;
+  int rot_off, nrot, ndef, rev;   // rev: columns stored in descending order of the roots (the root of the tree)
   double rho;
 };
 
@@ -634,14 +634,15 @@ __global__ void dc_rotate(const MergeDesc* __restrict__ descs, const int* __rest
 }
 
 // One wave per root of 1 + rho * sum_i w_i^2/(dlam_i - lambda) = 0.
-// Writes lambda_j and delta_ij = dlam_i - lambda_j (row = rowpos(i), col = cpos(j)).
+// Writes lambda_j and the pair (dorg_j, tau_j) with lambda_j = dorg_j + tau_j, dorg_j the pole the root is measured
+// from: delta_ij = dlam_i - lambda_j is evaluated where it is needed as (dlam_i - dorg_j) - tau_j, the form that
+// keeps its relative accuracy (LAPACK dlaed4's delta), instead of being stored as a K x K matrix -- at the root of an
+// N = 20 000 decomposition that matrix was 1.7 GB written row-scattered here and read column-strided by dc_zhat.
 __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ descs,
                                                   const double* __restrict__ dlam,
                                                   const double* __restrict__ w,
-                                                  const int* __restrict__ rowpos,
-                                                  const int* __restrict__ cpos,
-                                                  double* __restrict__ U, int64_t ld,
-                                                  double* __restrict__ lam) {
+                                                  double* __restrict__ lam, double* __restrict__ dorg_out,
+                                                  double* __restrict__ tau_out) {
   const MergeDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -718,19 +719,20 @@ __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ 
     x = (xn > lo && xn < hi) ? xn : mid;
   }
   const double tau = sgn * 0.5 * (lo + hi);
-  if (lane == 0) lam[base + j] = dorg + tau;
-  const int64_t col = base + cpos[base + j];
-  for (int i = lane; i < K; i += 64)
-    U[(base + rowpos[base + i]) + col * ld] = (dl[i] - dorg) - tau;
+  if (lane == 0) {
+    lam[base + j] = dorg + tau;
+    dorg_out[base + j] = dorg;
+    tau_out[base + j] = tau;
+  }
 }
 
-// Loewner: zhat_i = sign(w_i) sqrt| delta_ii * prod_{j != i} delta_ij / (dlam_i - dlam_j) |
+// Loewner: zhat_i = sign(w_i) sqrt| delta_ii * prod_{j != i} delta_ij / (dlam_i - dlam_j) |, delta_ij from the roots'
+// (dorg_j, tau_j) pairs: everything this reads is K-long and cache-resident. One wave per pole (row rowpos(i)).
 __global__ __launch_bounds__(256) void dc_zhat(const MergeDesc* __restrict__ descs,
                                                const double* __restrict__ dlam,
                                                const double* __restrict__ w,
                                                const int* __restrict__ pole_of_row,
-                                               const int* __restrict__ cpos,
-                                               const double* __restrict__ U, int64_t ld,
+                                               const double* __restrict__ dorg, const double* __restrict__ tau,
                                                double* __restrict__ zhat) {
   const MergeDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;
@@ -742,27 +744,33 @@ __global__ __launch_bounds__(256) void dc_zhat(const MergeDesc* __restrict__ des
   const double di = dlam[base + i];
   double p = 1.0;
   for (int j = lane; j < K; j += 64) {
-    const double delta = U[(base + r) + (int64_t)(base + cpos[base + j]) * ld];
+    const double delta = (di - dorg[base + j]) - tau[base + j];
     p *= (j == i) ? delta : delta / (di - dlam[base + j]);
   }
   p = wprod(p);
   if (lane == 0) zhat[base + r] = copysign(sqrt(fabs(p)), w[base + i]);
 }
 
-// U[:,cp] = normalised zhat / delta[:,cp]   (one block per kept column)
+// U[:,cp] = normalised zhat / delta[:,cp]   (one block per kept column; row r <-> pole pole_of_row(r), column cp <->
+// root cp, or root K-1-cp where the columns are stored in descending order: the root of the tree, MergeDesc::rev)
 __global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ descs,
                                                   const double* __restrict__ zhat,
+                                                  const double* __restrict__ dlam,
+                                                  const int* __restrict__ pole_of_row,
+                                                  const double* __restrict__ dorg, const double* __restrict__ tau,
                                                   double* __restrict__ U, int64_t ld) {
   __shared__ double sh[4];
   const MergeDesc d = descs[blockIdx.y];
   const int cp = blockIdx.x;
   if (cp >= d.Kneed) return;
   const int base = d.s;
+  const int j = d.rev ? d.K - 1 - cp : cp;
+  const double dj = dorg[base + j], tj = tau[base + j];
   double* u = U + base + (int64_t)(base + cp) * ld;
   const double* zh = zhat + base;
   double ss = 0.0;
   for (int r = threadIdx.x; r < d.K; r += 256) {
-    const double v = zh[r] / u[r];
+    const double v = zh[r] / ((dlam[base + pole_of_row[base + r]] - dj) - tj);
     u[r] = v;
     ss += v * v;
   }
@@ -888,6 +896,7 @@ __global__ void gather_cols(int n, int nv, const int* __restrict__ src, const do
 struct Node {
   int s, m, left, right, depth;
   std::vector<double> dv;  // eigenvalue of storage column s+t
+  int ksorted = 0;         // dv[0 .. ksorted) is ascending (the secular roots of the merge that produced the node)
 };
 
 // host side of one merge (LAPACK dlaed2's scan, re-derived): fills the packed
@@ -907,28 +916,41 @@ struct LazyLevel {
 };
 
 void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, MergeDesc& md,
-                LevelArrays& A, std::vector<double>& defvals, std::vector<int>& types_out) {
+                LevelArrays& A, std::vector<double>& defvals) {
   const int n1 = L.m, n2 = R.m, m = n1 + n2, s = L.s;
   const double theta = (ecut >= 0.0) ? 1.0 : -1.0;
   const double rho = 2.0 * std::fabs(ecut);
-  std::vector<double> z(m), D(m);
+  // scratch reused across the merges of a level (thousands of small merges at the bottom of the tree)
+  static thread_local std::vector<double> z, D;
+  static thread_local std::vector<std::pair<double, int>> keyed;
+  static thread_local std::vector<int> order, typ, nd, df;
+  z.resize(m); D.resize(m); keyed.resize(m); order.resize(m); typ.resize(m);
+  nd.clear(); df.clear();
   const double isq2 = 1.0 / std::sqrt(2.0);
+  double dmax = 0.0, zmax = 0.0;
   for (int t = 0; t < m; ++t) {
     z[t] = zraw[s + t] * ((t < n1) ? 1.0 : theta) * isq2;
     D[t] = (t < n1) ? L.dv[t] : R.dv[t - n1];
-  }
-  std::vector<int> order(m);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
-  double dmax = 0.0, zmax = 0.0;
-  for (int t = 0; t < m; ++t) {
+    keyed[t] = {D[t], t};
+    typ[t] = (t < n1) ? 1 : 3;
     dmax = std::max(dmax, std::fabs(D[t]));
     zmax = std::max(zmax, std::fabs(z[t]));
   }
+  // ascending in D, ties in storage order: what a stable sort of the indices gives, on (value, index) pairs. Each
+  // child's list is its ascending secular roots followed by its deflated values: only the two tails are sorted, the
+  // four runs are merged (the root of an N = 20 000 tree: 0.25 instead of 0.7 ms)
+  {
+    int kl = std::min(L.ksorted, n1), kr = std::min(R.ksorted, m - n1);
+    if (!std::is_sorted(keyed.begin(), keyed.begin() + kl)) kl = 0;          // (never seen; costs O(K))
+    if (!std::is_sorted(keyed.begin() + n1, keyed.begin() + n1 + kr)) kr = 0;
+    std::sort(keyed.begin() + kl, keyed.begin() + n1);
+    std::sort(keyed.begin() + n1 + kr, keyed.end());
+    std::inplace_merge(keyed.begin(), keyed.begin() + kl, keyed.begin() + n1);
+    std::inplace_merge(keyed.begin() + n1, keyed.begin() + n1 + kr, keyed.end());
+    std::inplace_merge(keyed.begin(), keyed.begin() + n1, keyed.end());
+  }
+  for (int t = 0; t < m; ++t) order[t] = keyed[t].second;
   const double tol = 8.0 * DEPS * std::max(dmax, zmax);
-  std::vector<int> typ(m);
-  for (int t = 0; t < m; ++t) typ[t] = (t < n1) ? 1 : 3;
-  std::vector<int> nd, df;
   md.s = s; md.n1 = n1; md.m = m; md.rho = rho;
   md.rot_off = (int)A.ra.size(); md.nrot = 0;
   if (rho * zmax <= tol) {
@@ -983,7 +1005,6 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
     A.defdst[s + q] = K + q;
     defvals[q] = D[df[q]];
   }
-  types_out = typ;
 }
 
 int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
@@ -1042,7 +1063,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   BK_CHECK_LAUNCH();
   // double arrays: z, dlam, w, lam, zhat, rc, rs  (7n) ; int arrays: 8n ; descs
   void* pd = nullptr;
-  BK_TRY(ws_get(ctx, SLOT_EIG_MISC, (int64_t)12 * n * sizeof(double), &pd));
+  BK_TRY(ws_get(ctx, SLOT_EIG_MISC, (int64_t)14 * n * sizeof(double), &pd));
   double* d_z = (double*)pd;
   double* d_dlam = d_z + n;
   double* d_w = d_dlam + n;
@@ -1054,6 +1075,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   double* d_gl = d_gf + n;
   double* d_of = d_gl + n;
   double* d_ol = d_of + n;
+  double* d_dorg = d_ol + n;    // per root: the pole it is measured from, and its offset from that pole
+  double* d_tau = d_dorg + n;
   void* pi = nullptr;
   BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)11 * n * sizeof(int), &pi));
   int* d_rowpos = (int*)pi;
@@ -1141,6 +1164,13 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     const int nm = (int)ids.size();
     if (nm == 0) continue;
     const auto t_level = std::chrono::steady_clock::now();
+    auto t_mark = t_level;
+    double ms_split[5] = {0, 0, 0, 0, 0};   // (verbose) wait for z | host scans | uploads + secular | wait for the roots | rest
+    auto lap = [&](int slot) {
+      const auto now = std::chrono::steady_clock::now();
+      ms_split[slot] += std::chrono::duration<double, std::milli>(now - t_mark).count();
+      t_mark = now;
+    };
     std::vector<MergeDesc> descs(nm);
     int max_m = 0;
     for (int q = 0; q < nm; ++q) {
@@ -1182,18 +1212,18 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       BK_HIP(hipStreamSynchronize(st));
     }
 
+    lap(0);
     // host deflation scans
     A.ra.clear(); A.rb.clear(); A.rc.clear(); A.rs.clear();
     std::vector<std::vector<double>> defvals(nm);
     std::vector<int> rot_merges;
     int maxK = 0, max_ndef = 0;
-    std::vector<int> typ;
     for (int q = 0; q < nm; ++q) {
       const Node& P = nodes[ids[q]];
       const Node& Ln = nodes[P.left];
       const Node& Rn = nodes[P.right];
       const int cut = P.s + Ln.m - 1;
-      host_merge(Ln, Rn, he[cut], hz.data(), descs[q], A, defvals[q], typ);
+      host_merge(Ln, Rn, he[cut], hz.data(), descs[q], A, defvals[q]);
       if (descs[q].nrot > 0) rot_merges.push_back(q);
       maxK = std::max(maxK, descs[q].K);
       max_ndef = std::max(max_ndef, descs[q].ndef);
@@ -1203,6 +1233,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       // store roots in descending order so that the kept ones are a prefix
       const int K = descs[0].K, s = descs[0].s;
       for (int j = 0; j < K; ++j) A.cpos[s + j] = K - 1 - j;
+      descs[0].rev = 1;
     }
     if (lazy_level && !is_root) {
       // the deflation rotations act on the columns of the children's matrices, hence on yf, yl
@@ -1219,13 +1250,12 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         }
       }
     }
+    lap(1);
     BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_dlam, A.dlam.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_w, A.w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_rowpos, A.rowpos.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_pole, A.pole_of_row.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_srccol, A.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_cpos, A.cpos.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_defsrc, A.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     BK_HIP(hipMemcpyAsync(d_defdst, A.defdst.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
     const int nrot_total = (int)A.ra.size();
@@ -1250,18 +1280,20 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         const int nb = std::min(65535, nm - b0);
         hipLaunchKernelGGL(dc_secular, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_dlam,
-                           (const double*)d_w, (const int*)d_rowpos, (const int*)d_cpos, U, N, d_lam);
+                           (const double*)d_w, d_lam, d_dorg, d_tau);
         hipLaunchKernelGGL(dc_zhat, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_dlam,
-                           (const double*)d_w, (const int*)d_pole, (const int*)d_cpos,
-                           (const double*)U, N, d_zhat);
+                           (const double*)d_w, (const int*)d_pole, (const double*)d_dorg,
+                           (const double*)d_tau, d_zhat);
       }
       BK_CHECK_LAUNCH();
+      lap(2);
       PinnedFetch pf(ctx, (int64_t)n);
       BK_TRY(pf.add(hlam.data(), d_lam, n * sizeof(double)));
       BK_TRY(pf.finish());
     }
     BK_HIP(hipStreamSynchronize(st));
+    lap(3);
     // new eigenvalue lists in storage order
     for (int q = 0; q < nm; ++q) {
       Node& P = nodes[ids[q]];
@@ -1276,6 +1308,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         P.dv[A.cpos[s + j]] = lv;
       }
       for (int t = 0; t < P.m - K; ++t) P.dv[K + t] = defvals[q][t];
+      P.ksorted = (depth == 0) ? 0 : K;      // (the root stores its roots in descending order)
       nodes[P.left].dv.clear(); nodes[P.left].dv.shrink_to_fit();
       nodes[P.right].dv.clear(); nodes[P.right].dv.shrink_to_fit();
     }
@@ -1317,7 +1350,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
         hipLaunchKernelGGL(dc_vectors, dim3(maxKneed, nb), dim3(256), 0, st,
-                           (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, U, N);
+                           (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, (const double*)d_dlam,
+                           (const int*)d_pole, (const double*)d_dorg, (const double*)d_tau, U, N);
       }
       BK_CHECK_LAUNCH();
     }
@@ -1414,10 +1448,13 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     // host vectors (gd, descs) must outlive the async copies
     BK_HIP(hipStreamSynchronize(st));
     if (!lazy_level) std::swap(Qc, Qn);
+    lap(4);
     if (verbose)
-      fprintf(stderr, "[bigkrls]   d&c depth %2d%s: %6d merges, largest %6d (non-deflated %6d, %d rotations) %8.2f ms\n",
+      fprintf(stderr, "[bigkrls]   d&c depth %2d%s: %6d merges, largest %6d (non-deflated %6d, %d rotations) %8.2f ms"
+                      "  [wait z %.2f | host scans %.2f | upload+launch %.2f | wait roots %.2f | vectors %.2f]\n",
               depth, lazy_level ? " (factored)" : "", nm, max_m, maxK, (int)A.ra.size(),
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count(),
+              ms_split[0], ms_split[1], ms_split[2], ms_split[3], ms_split[4]);
   }
   if (n == 1) {
     vals_desc.assign(1, dadj[0]);
