@@ -152,6 +152,7 @@ enum Slot {
   SLOT_DIST_MISC = 39,     // ... panel strips and the Y = A22 V exchange buffers
   SLOT_DIST_K = 40,        // ... this rank's column block of K when the caller does not want it back
   SLOT_DIST_V = 41,        // ... column blocks of the variance matrices (same)
+  SLOT_EIG_FLAGS = 42,     // completion flags of the persistent stage-2 back-transform's tasks
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);

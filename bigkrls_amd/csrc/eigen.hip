@@ -2341,6 +2341,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   std::vector<int64_t> bt2_toff;      // (source of an asynchronous copy: lives until the function returns)
   double* bt2_T = nullptr;
   int64_t* bt2_dtoff = nullptr;
+  int* bt2_err = nullptr;             // watchdog word of the persistent stage-2 back-transform (when it ran)
   Bt1Plan bt1;
   double *bt1_V = nullptr, *bt1_T = nullptr;
   Stage1Ws s1{};
@@ -2554,7 +2555,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     if (pnv > 0 && two_stage) {
       tick("gather kept columns");
       if (bt2_T != nullptr || bt1_V != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
-      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv, bt2_dtoff, bt2_T));
+      // (the watchdog word of the bulge chasing, read back as zero above, now serves the persistent back-transform)
+      bt2_err = (bt2_T != nullptr) ? (int*)scratch : nullptr;
+      BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv, bt2_dtoff, bt2_T,
+                                   bt2_toff.empty() ? 0 : bt2_toff.back(), bt2_err));
       tick("back-transform stage 2");
       void* pw12 = nullptr;
       BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * BT1_GRP * S2_B * pnv * sizeof(double), &pw12));
@@ -2571,6 +2575,26 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   }
   if (bt2_T != nullptr || bt1_V != nullptr)
     BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
+  if (bt2_err != nullptr) {
+    // watchdog word of the persistent stage-2 back-transform: Z is garbage if it fired -> the decomposition is redone
+    // with per-wavefront launches (by the caller's replay in the distributed fit)
+    int h_err3 = 0;
+    PinnedFetch pf3(ctx, 1);
+    BK_TRY(pf3.add(&h_err3, bt2_err, sizeof(int)));
+    BK_TRY(pf3.finish());
+#ifdef BK_FAULT_INJECT
+    const char* fault = getenv("BIGKRLS_FAULT");
+    if (fault && std::string(fault) == "watchdog_bt2" && !ctx->no_resident) h_err3 = 1;
+#endif
+    if (h_err3 != 0 && mode == EIG_RESUME) {
+      set_error("eigen: watchdog of the persistent stage-2 back-transform fired after the distributed stage 1");
+      return BK_EWATCHDOG;
+    }
+    if (h_err3 != 0)
+      return eigen_retry_without_resident(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv,
+                                          h_n_vecs, part_index, part_count);
+    return BIGKRLS_OK;
+  }
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
 }
