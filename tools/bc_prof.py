@@ -21,7 +21,8 @@ lib.bigkrls_debug_bc_prof(acc, 1)
 ops.bEigen(K, None, 0.001)
 lib.bigkrls_debug_bc_prof(acc, 0)
 names = ["wait for the reflector (+ its barrier)", "partial products p, y", "wait for the entering column (+ barrier)",
-         "reflector generation, q, sends (+ barrier)", "u, z, window update", "-", "-", "end-of-sweep barrier, loop"]
+         "reflector generation, q, sends (+ barrier)", "u, z, window update",
+         "new last row / first column export (bc_regwin)", "-", "end-of-sweep barrier, loop"]
 a = np.array(list(acc), dtype=float)
 sweeps = n - 2 - (n // 64 // 3) * 64          # sweeps the profiled location (a third of the way down) takes part in
 tot = a.sum()

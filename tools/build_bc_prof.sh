@@ -4,9 +4,9 @@
 set -e
 cd "$(dirname "$0")/../bigkrls_amd/csrc"
 mkdir -p /tmp/bcprof_obj
-for f in capi gemm vecops solveforc deriv eigen neff fit; do
+for f in capi gemm vecops solveforc deriv eigen neff fit dist; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DBK_BC_PROF -c $f.hip -o /tmp/bcprof_obj/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libbigkrls_bcprof.so /tmp/bcprof_obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libbigkrls_bcprof.so /tmp/bcprof_obj/*.o -ldl
 echo built tools/libbigkrls_bcprof.so
