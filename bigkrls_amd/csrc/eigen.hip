@@ -2741,9 +2741,15 @@ int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int
 // profiling builds only (tools/bc_prof.py): the accumulated shader clocks of one bc_resident location per phase
 extern "C" int bigkrls_debug_bc_prof(long long* out8, int reset) {
   if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(bk::bc_prof_acc), 8 * sizeof(long long)) != hipSuccess) return 1;
+  if (out8) {   // slot 5 of the LDS-window kernel is unused: the column's send -> receipt time (10-ns ticks) travels there
+    unsigned long long st[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(bk::bc_prof_stamp), sizeof st) != hipSuccess) return 1;
+    if (getenv("BIGKRLS_BC_PROF_FLIGHT")) out8[5] = (long long)st[3];
+  }
   if (reset) {
     long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(bk::bc_prof_acc), z, sizeof z) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bk::bc_prof_stamp), z, 4 * sizeof(long long)) != hipSuccess) return 1;
   }
   return 0;
 }

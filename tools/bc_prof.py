@@ -25,9 +25,13 @@ names = ["wait for the reflector (+ its barrier)", "partial products p, y", "wai
          "new last row / first column export (bc_regwin)", "-", "end-of-sweep barrier, loop"]
 a = np.array(list(acc), dtype=float)
 sweeps = n - 2 - (n // 64 // 3) * 64          # sweeps the profiled location (a third of the way down) takes part in
-tot = a.sum()
+tot = a.sum() - a[6] - (a[5] if os.environ.get('BIGKRLS_BC_PROF_FLIGHT') else 0)
 print(f"N={n}: location {n // 64 // 3} of {n // 64}, ~{sweeps} sweeps, {tot / sweeps:.0f} clocks per sweep "
       f"({tot / sweeps / 2.1e3:.2f} us at 2.1 GHz)")
-for nm, v in zip(names, a):
-    if v > 0:
+for k, (nm, v) in enumerate(zip(names, a)):
+    if v > 0 and k != 6:
         print(f"  {nm:46s} {v / sweeps:8.0f} clocks  {100 * v / tot:5.1f} %")
+if a[6] > 0:
+    print(f"  reflector: send -> receipt at the next location {10.0 * a[6] / sweeps:8.0f} ns per sweep (100 MHz stamps)")
+if os.environ.get("BIGKRLS_BC_PROF_FLIGHT"):
+    print(f"  column:    send -> receipt at the previous location {10.0 * a[5] / sweeps:8.0f} ns per sweep")
