@@ -998,6 +998,48 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
   return ldexp(fma(t, p, t), n >> 5);
 }
 
+// XCD-aware, L2-blocked order of the one-wave-per-tile kernel builds. Consecutive workgroups round-robin over the 8
+// XCDs, so with the plain tile order every XCD walks the whole matrix and streams all of X through its 4 MB L2 again
+// and again (X is 8 MB at N = 50 000, P = 20: 1.14 x the algorithmic bytes moved, profiles/r03/r03k_kernel_build_pmc.log).
+// Here the tiles are ordered band by band (a band = R consecutive tile rows, whose R x 32 rows of X take ~1 MB),
+// inside a band column by column, and every XCD takes one contiguous eighth of that sequence (xcd_remap): it keeps its
+// band's row panels in its L2 and streams each column panel once -- the order of the trailing update (SyrkMap), in
+// closed form because a launch has up to millions of 32 x 32 tiles.
+// Lower triangle of `tiles` tile rows: band b = rows [bR, min((b+1)R, tiles)), columns 0 .. r1-1, column tn holding
+// the rows max(r0, tn) .. r1-1. Full bands before b hold R^2 b(b-1)/2 + b R(R+1)/2 tiles.
+__device__ __forceinline__ void band_major_lower(int64_t sq, int tiles, int R, int& tm, int& tn) {
+  const double Rd = (double)R;
+  // start(b) = R^2 b(b-1)/2 + b R(R+1)/2 = (R^2/2) b^2 + (R/2) b  ->  b = floor of the positive root, then corrected
+  int b = (int)((-0.5 * Rd + sqrt(0.25 * Rd * Rd + 2.0 * Rd * Rd * (double)sq)) / (Rd * Rd));
+  auto start = [&](int q) { return (int64_t)R * R * q * (q - 1) / 2 + (int64_t)q * R * (R + 1) / 2; };
+  while (b > 0 && start(b) > sq) --b;
+  while ((int64_t)(b + 1) * R < tiles && start(b + 1) <= sq) ++b;
+  const int r0 = b * R, r1 = min(r0 + R, tiles), Rb = r1 - r0;
+  int64_t sp = sq - start(b);
+  const int64_t nfull = (int64_t)r0 * Rb;                 // the columns left of the band's diagonal corner
+  if (sp < nfull) {
+    tn = (int)(sp / Rb);
+    tm = r0 + (int)(sp % Rb);
+    return;
+  }
+  sp -= nfull;                                            // corner: column r0 + c holds Rb - c rows
+  int c = (int)(((2.0 * Rb + 1.0) - sqrt((2.0 * Rb + 1.0) * (2.0 * Rb + 1.0) - 8.0 * (double)sp)) * 0.5);
+  auto cstart = [&](int q) { return (int64_t)q * Rb - (int64_t)q * (q - 1) / 2; };
+  while (c > 0 && cstart(c) > sp) --c;
+  while (c + 1 < Rb && cstart(c + 1) <= sp) ++c;
+  tn = r0 + c;
+  tm = tn + (int)(sp - cstart(c));
+}
+// rectangle of tiles_m x tiles_n tiles: bands of R tile rows, inside a band column by column
+__device__ __forceinline__ void band_major_rect(int64_t sq, int tiles_m, int tiles_n, int R, int& tm, int& tn) {
+  const int64_t per_band = (int64_t)R * tiles_n;
+  const int b = (int)(sq / per_band);
+  const int r0 = b * R, Rb = min(R, tiles_m - r0);
+  const int64_t sp = sq - (int64_t)b * per_band;
+  tn = (int)(sp / Rb);
+  tm = r0 + (int)(sp % Rb);
+}
+
 // Small-P variant (P <= 128: the fit's own regime, P = 5..50): the operands are a few
 // MB and live in L2, the output is 8 N^2 bytes, so the kernel is HBM-write bound and the
 // only job is to keep many independent store streams in flight. No LDS, no barriers:
@@ -1009,14 +1051,16 @@ template <int KS>
 __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
     const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V,
     int P, const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma,
-    double* __restrict__ out, int64_t ldo, int64_t diag_shift, int tiles_m, int64_t ntiles) {
+    double* __restrict__ out, int64_t ldo, int64_t diag_shift, int tiles_m, int tiles_n, int band_rows,
+    int64_t ntiles) {
   __shared__ double etab[32];
   if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t w = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (w >= ntiles) return;
-  const int tm = (int)(w % tiles_m), tn = (int)(w / tiles_m);
+  int tm, tn;
+  band_major_rect(w, tiles_m, tiles_n, band_rows, tm, tn);
   const int m0 = tm * 32, n0 = tn * 32;
   const int lm = lane & 15, lk = lane >> 4;
   d4 acc[2][2];
@@ -1185,19 +1229,16 @@ __device__ __forceinline__ void kb_store_tile(double* __restrict__ out, int64_t 
 template <int KS>
 __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
     const double* __restrict__ A, int64_t lda, int U, int P, const double* __restrict__ na,
-    double neg_inv_sigma, double* __restrict__ out, int64_t ldo, int tiles, int64_t ntiles) {
+    double neg_inv_sigma, double* __restrict__ out, int64_t ldo, int tiles, int band_rows, int64_t ntiles) {
   __shared__ double tbuf[4][32 * 33];
   __shared__ double etab[32];
   if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t w = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
   if (w >= ntiles) return;
-  // lower-triangular tiles column by column: column c starts at c*tiles - c(c-1)/2
-  int tn = (int)((2.0 * tiles + 1.0 - sqrt((2.0 * tiles + 1.0) * (2.0 * tiles + 1.0) - 8.0 * (double)w)) * 0.5);
-  while (tn > 0 && (int64_t)tn * tiles - (int64_t)tn * (tn - 1) / 2 > w) --tn;
-  while ((int64_t)(tn + 1) * tiles - (int64_t)(tn + 1) * tn / 2 <= w) ++tn;
-  const int tm = tn + (int)(w - ((int64_t)tn * tiles - (int64_t)tn * (tn - 1) / 2));
+  int tm, tn;
+  band_major_lower(w, tiles, band_rows, tm, tn);
   const int m0 = tm * 32, n0 = tn * 32;
   const int lm = lane & 15, lk = lane >> 4;
   d4 acc[2][2];
@@ -1504,6 +1545,15 @@ __global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
     }
 }
 
+// tile rows per band of the wave kernels' order: the band's rows of X (R x 32 x P doubles) take about 1 MB of an XCD's
+// 4 MB L2 (BIGKRLS_KB_R overrides; a value >= the number of tile rows gives the plain column-by-column order)
+static int kb_band_rows(int64_t p, int tiles) {
+  static const int r_env = [] { const char* e = getenv("BIGKRLS_KB_R"); return e ? atoi(e) : 0; }();
+  int64_t R = r_env > 0 ? r_env : (1 << 20) / (32 * 8 * std::max<int64_t>(p, 1));
+  R = std::max<int64_t>(8, std::min<int64_t>(R, 1024));
+  return (int)std::min<int64_t>(R, std::max(tiles, 1));
+}
+
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift) {
@@ -1573,9 +1623,10 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
     const int ks = (steps + chunks - 1) / chunks;
     BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
     const dim3 grid((unsigned)((ntiles + 3) / 4));
+    const int band_rows = kb_band_rows(p, tiles);
 #define BK_KBS(KS)                                                                                 \
   hipLaunchKernelGGL(kernel_block_sym_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u,   \
-                     (int)p, (const double*)pna, -1.0 / sigma, out, ldo, tiles, ntiles)
+                     (int)p, (const double*)pna, -1.0 / sigma, out, ldo, tiles, band_rows, ntiles)
     switch (ks) {
       case 1: BK_KBS(1); break;
       case 2: BK_KBS(2); break;
@@ -1600,10 +1651,11 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
     const int ks = (steps + chunks - 1) / chunks;  // 1..8 MFMA steps per chunk, minimal padding
     BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
     const dim3 grid((unsigned)((ntiles + 3) / 4));
+    const int band_rows = kb_band_rows(p, tiles_m);
 #define BK_KBW(KS)                                                                                  \
   hipLaunchKernelGGL(kernel_block_wave_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u, B, \
                      ldb, (int)v, (int)p, (const double*)pna, (const double*)pnb, -1.0 / sigma, out,  \
-                     ldo, diag_shift, tiles_m, ntiles)
+                     ldo, diag_shift, tiles_m, tiles_n, band_rows, ntiles)
     switch (ks) {
       case 1: BK_KBW(1); break;
       case 2: BK_KBW(2); break;
