@@ -1693,15 +1693,15 @@ __global__ void kry_fill_random(double* __restrict__ p, int64_t total, unsigned 
 
 // out[c] = || KQ[:, c] - theta[c] Q[:, c] ||^2, one workgroup per column (the true residual of a Ritz pair)
 __global__ __launch_bounds__(256) void kry_resid_sq_kernel(const double* __restrict__ KQ, const double* __restrict__ Q,
-                                                            const double* __restrict__ theta, int64_t n,
-                                                            double* __restrict__ out) {
+                                                            const double* __restrict__ theta, int64_t n, int64_t row0,
+                                                            int64_t nrows, double* __restrict__ out) {
   __shared__ double part[4];
   const int c = blockIdx.x, tid = threadIdx.x;
   const double th = theta[c];
-  const double* kq = KQ + (int64_t)c * n;
-  const double* q = Q + (int64_t)c * n;
+  const double* kq = KQ + (int64_t)c * n + row0;      // (multi-GPU: the sum over this rank's rows)
+  const double* q = Q + (int64_t)c * n + row0;
   double acc = 0.0;
-  for (int64_t i = tid; i < n; i += 256) {
+  for (int64_t i = tid; i < nrows; i += 256) {
     const double r = kq[i] - th * q[i];
     acc += r * r;
   }
@@ -1834,10 +1834,15 @@ __global__ void kry_assemble_t(const double* __restrict__ Aall, const double* __
 // gets the triangular factor with W_in = W_out Rout. tmp is an n x b scratch, dG holds 4 b^2 doubles
 // and an int. Everything runs on the device (Gram matrix, factorisation and inverse in one workgroup,
 // W R^-1 as a GEMM); one synchronisation at the end brings Rout and the breakdown flag to the host.
+// Multi-GPU (comm != nullptr): the rows [ro, ro + nr) of W are this rank's; the Gram matrix is the all-reduced sum of
+// the ranks' W_loc' W_loc (128 x 128 doubles per pass), its factorisation is replicated (identical input, deterministic
+// kernel: identical factors on every rank) and W_loc R^-1 is local -- CholeskyQR2 in its communication-avoiding form.
 int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, double* dG,
-               std::vector<double>& Rout, bool* breakdown, double* dRkeep = nullptr) {
+               std::vector<double>& Rout, bool* breakdown, double* dRkeep = nullptr, bigkrls_comm* comm = nullptr,
+               int64_t ro = 0, int64_t nr = -1) {
   hipStream_t st = ctx->stream;
   BK_REQUIRE(b <= KRY_B, "kry_cholqr: block too wide");
+  if (nr < 0) nr = n;
   double* dR1 = dG + (int64_t)b * b;
   double* dR2 = dR1 + (int64_t)b * b;
   double* dRacc = dR2 + (int64_t)b * b;
@@ -1845,10 +1850,12 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
   *breakdown = false;
   BK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
   for (int pass = 0; pass < 2; ++pass) {
-    BK_TRY(gemm(ctx, 1, 0, b, b, n, 1.0, *W, n, *W, n, 0.0, dG, b));
+    if (nr > 0) BK_TRY(gemm(ctx, 1, 0, b, b, nr, 1.0, *W + ro, n, *W + ro, n, 0.0, dG, b));
+    else BK_HIP(hipMemsetAsync(dG, 0, (size_t)b * b * sizeof(double), st));
+    if (comm) BK_TRY(comm_all_reduce(comm, dG, (int64_t)b * b, COMM_SUM));
     hipLaunchKernelGGL(kry_chol_inv_kernel, dim3(1), dim3(256), 0, st, dG, b, pass == 0 ? dR1 : dR2, dflag);
     BK_CHECK_LAUNCH();
-    BK_TRY(gemm(ctx, 0, 0, n, b, b, 1.0, *W, n, dG, b, 0.0, *tmp, n));
+    if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, b, 1.0, *W + ro, n, dG, b, 0.0, *tmp + ro, n));
     std::swap(*W, *tmp);
   }
   BK_TRY(gemm(ctx, 0, 0, b, b, b, 1.0, dR2, b, dR1, b, 0.0, dRacc, b));   // Rout = R2 R1
@@ -1918,12 +1925,18 @@ struct KTimes {
   int64_t r0 = 0, r1 = 0, nb = 0;
 };
 
-static int k_times(bigkrls_ctx* ctx, const KTimes& op, int64_t n, const double* B, int64_t cols, double* W) {
+// Multi-GPU: every n-row array of the iteration (the basis B, W, the Ritz vectors) is ROW-SHARDED in place -- rank r
+// computes and reads only its rows [r0, r1) of it, the other rows are not valid. The one product that needs whole
+// columns is this one: the block's rows are all-gathered (in place: n x cols doubles per step, the exchange
+// north_star names), then W[r0:r1, :] = K[r0:r1, :] B from this rank's column block of K. Nothing of W is gathered:
+// the re-orthogonalisation, the Cholesky QR and the Ritz vectors work on the row blocks and all-reduce their small
+// Gram / coefficient matrices.
+static int k_times(bigkrls_ctx* ctx, const KTimes& op, int64_t n, double* B, int64_t cols, double* W) {
   if (!op.comm) return gemm(ctx, 0, 0, n, cols, n, 1.0, op.A, op.lda, B, n, 0.0, W, n);
   const int64_t nloc = op.r1 - op.r0;
-  // the local rows go straight into their place in W; the gather then overwrites all of W (own rows unchanged)
+  BK_TRY(comm_gather_rows(op.comm, B + op.r0, nloc, n, cols, op.nb, n, B, n));
   if (nloc > 0) BK_TRY(gemm(ctx, 1, 0, nloc, cols, n, 1.0, op.Kcols, n, B, n, 0.0, W + op.r0, n));
-  return comm_gather_rows(op.comm, W + op.r0, nloc, n, cols, op.nb, n, W, n);
+  return BIGKRLS_OK;
 }
 
 // control decisions of the iteration (breakdown, convergence, verification) on values agreed by all ranks: a
@@ -1961,6 +1974,16 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   double* B = (double*)pB;
   double* W = (double*)pW;
   double* W2 = W + n * std::max<int64_t>(b, k);
+  // this rank's rows of every n-row array (see k_times); one GPU: all of them
+  bigkrls_comm* const comm = kop.comm;
+  const int64_t ro = comm ? kop.r0 : 0, nr = comm ? kop.r1 - kop.r0 : n;
+  // C (rows x cols, ld rows) = sum over the ranks of  Xloc' Yloc  (X: n x rows, Y: n x cols, ld n)
+  auto gram = [&](const double* X, int64_t rows, const double* Y, int64_t cols, double* Cout) -> int {
+    if (nr > 0) BK_TRY(gemm(ctx, 1, 0, rows, cols, nr, 1.0, X + ro, n, Y + ro, n, 0.0, Cout, rows));
+    else BK_HIP(hipMemsetAsync(Cout, 0, (size_t)(rows * cols) * sizeof(double), st));
+    if (comm) BK_TRY(comm_all_reduce(comm, Cout, rows * cols, COMM_SUM));
+    return BIGKRLS_OK;
+  };
   double* C = (double*)pC;
   double* dG = C + maxdim * b;            // Cholesky-QR scratch: Gram / inverse, R1, R2, R2 R1, flag
   double* dA = dG + 4 * b * b + 8;
@@ -1971,7 +1994,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   bool breakdown = false;
   // ---- B_0 ----------------------------------------------------------------------------------
   BK_TRY(fill_random(ctx, W, n * b, 20240229u));
-  BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown));
+  BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, nullptr, comm, ro, nr));
   {
     double okv = breakdown ? 0.0 : 1.0;
     BK_TRY(kry_agree_min(kop, &okv, 1));
@@ -1996,20 +2019,20 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   if (const char* fc = getenv("BIGKRLS_KRY_FIRST_CHECK")) next_check = std::max(2, atoi(fc));   // (development)
   while (true) {
     // ---- one block Lanczos step: W = K B_j, orthogonalised against every block so far (CGS2) ---
-    const double* Bj = B + (int64_t)steps * b * n;
+    double* Bj = B + (int64_t)steps * b * n;
     // (bench.py: HIP-event sampling of the step's dominant product, 2 n^2 b flops, every launch)
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_kb", 2.0 * (double)n * (double)n * b));
     BK_TRY(k_times(ctx, kop, n, Bj, b, W));
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_kb"));
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_cgs2", 8.0 * (double)n * (double)dim * b));
     for (int pass = 0; pass < 2; ++pass) {
-      BK_TRY(gemm(ctx, 1, 0, dim, b, n, 1.0, B, n, W, n, 0.0, C, dim));
+      BK_TRY(gram(B, dim, W, b, C));                       // (multi-GPU: local rows + one all-reduce of dim x 128)
       if (pass == 0)   // A_j = B_j' K B_j: rows [steps b, steps b + b) of the first coefficient block
         BK_TRY(copy_matrix(ctx, C + (int64_t)steps * b, b, b, dim, dAall + (int64_t)steps * b * b, b));
-      BK_TRY(gemm(ctx, 0, 0, n, b, dim, -1.0, B, n, C, dim, 1.0, W, n));
+      if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dim, -1.0, B + ro, n, C, dim, 1.0, W + ro, n));
     }
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_cgs2"));
-    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b));   // synchronises the stream
+    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b, comm, ro, nr));   // synchronises the stream
     ++steps;
     {
       double okv = breakdown ? 0.0 : 1.0;
@@ -2121,7 +2144,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   // which is what every call did before (BIGKRLS_KRY_REFINE=1 still forces it).
   double* Q = W;                        // n x k (W, W2 are n x max(b,k))
   double* KQ = W2;
-  BK_TRY(gemm(ctx, 0, 0, n, k, dim, 1.0, B, n, (double*)pY, dim, 0.0, Q, n));
+  if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, k, dim, 1.0, B + ro, n, (double*)pY, dim, 0.0, Q + ro, n));
   double* dH = dA + b * b;              // k x k + 2k
   double* dvalsH = dH + k * k;
   std::vector<double> hv(theta.begin(), theta.begin() + k);     // Ritz values of T, descending
@@ -2139,8 +2162,9 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     const double* dtheta = (const double*)pT + dim * dim;
     BK_TRY(k_times(ctx, kop, n, Q + c0 * n, bs, KQ));
     hipLaunchKernelGGL(kry_resid_sq_kernel, dim3((unsigned)bs), dim3(256), 0, st, (const double*)KQ,
-                       (const double*)(Q + c0 * n), dtheta + c0, n, dvalsH);
+                       (const double*)(Q + c0 * n), dtheta + c0, n, ro, nr, dvalsH);
     BK_CHECK_LAUNCH();
+    if (comm) BK_TRY(comm_all_reduce(comm, dvalsH, bs, COMM_SUM));       // the squared norms over all rows
     double* hp = nullptr;
     BK_TRY(pinned_get(ctx, bs, &hp));
     BK_HIP(hipMemcpyAsync(hp, dvalsH, bs * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2160,7 +2184,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   void* pZ = nullptr;
   if (refine) {
     BK_TRY(k_times(ctx, kop, n, Q, k, KQ));
-    BK_TRY(gemm(ctx, 1, 0, k, k, n, 1.0, Q, n, KQ, n, 0.0, dH, k));
+    BK_TRY(gram(Q, k, KQ, k, dH));
     BK_TRY(ws_get(ctx, SLOT_KRY_Y, std::max<int64_t>(dim * k, k * k) * sizeof(double), &pZ));
     int64_t nvZ = 0;
     BK_TRY(eigen(ctx, dH, k, k, k, dvalsH, k, -1.0, (double*)pZ, k, &nvZ, 0, 1, EIG_FULL));
@@ -2182,8 +2206,13 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   nv = std::min<int64_t>(nv, n_vecs_max);
   if (h_n_vecs) *h_n_vecs = nv;
   if (nv > 0) {
-    if (refine) BK_TRY(gemm(ctx, 0, 0, n, nv, k, 1.0, Q, n, (double*)pZ, k, 0.0, vecs, ldv));
-    else BK_TRY(copy_matrix(ctx, Q, n, nv, n, vecs, ldv));
+    if (nr > 0) {
+      if (refine) BK_TRY(gemm(ctx, 0, 0, nr, nv, k, 1.0, Q + ro, n, (double*)pZ, k, 0.0, vecs + ro, ldv));
+      else BK_TRY(copy_matrix(ctx, Q + ro, nr, nv, n, vecs + ro, ldv));
+    }
+    // every rank returns all rows of the kept eigenvectors (the later passes of the fit read row blocks of Q but
+    // build column blocks of Q diag(w) Q'): one all-gather of the row blocks, n x nv doubles
+    if (comm) BK_TRY(comm_gather_rows(comm, vecs + ro, nr, ldv, nv, kop.nb, n, vecs, ldv));
     const int64_t pc0 = nv * part_index / part_count, pc1 = nv * (part_index + 1) / part_count;
     if (pc0 > 0) BK_HIP(hipMemsetAsync(vecs, 0, (size_t)pc0 * ldv * sizeof(double), st));
     if (pc1 < nv) BK_HIP(hipMemsetAsync(vecs + pc1 * ldv, 0, (size_t)(nv - pc1) * ldv * sizeof(double), st));

@@ -1,5 +1,5 @@
 set -x
-O=gpurun_out/${EVID:-r03h}; mkdir -p $O
+O=gpurun_out/${EVID:-r04m}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q --durations=12 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
