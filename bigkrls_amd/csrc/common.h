@@ -277,7 +277,7 @@ int eigen_krylov_dist(bigkrls_comm* comm, const double* Kcols, int64_t n, int64_
 int dist_s1_open(bigkrls_ctx* ctx, int64_t n);
 int dist_s1_panel(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip);
 int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda, int64_t ncols,
-               double* Yout, int64_t ldy);
+               int64_t row0, double* Ypart, int64_t ldy);
 int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,
                    int64_t row0);
 // p[0 .. count) = uniform values in [-0.5, 0.5) from a counter-based generator (element index and seed only): the

@@ -197,8 +197,9 @@ int comm_gather_rows(bigkrls_comm* comm, const double* local, int64_t nloc, int6
 // ---------------------------------------------------------------------------------------------------------------
 // Dense symmetric eigendecomposition with stage 1 (dense -> band, 4/3 N^3 flops) partitioned by column blocks
 // ("Eigen, dense tridiagonalisation"). Per 64-column panel: one broadcast of the panel
-// strip from its owner, the replicated panel QR, this rank's rows of Y = A22 V (A22 symmetric: its own columns,
-// transposed), one all-gather of Y (N x 64), the replicated thin products, and the update of the own columns --
+// strip from its owner, the replicated panel QR, this rank's contribution to Y = A22 V (its own columns times its own
+// rows of V: the plain product along the block's contiguous dimension), one all-reduce of Y (N x 64), the replicated
+// thin products, and the update of the own columns --
 // with look-ahead: the columns of the NEXT panel are updated first by their owner, its strip is broadcast and its
 // factorisation started on the look-ahead stream beside the update of the remaining columns. The reduced matrix
 // ends up replicated; stage 2 and the divide & conquer are replicated (latency-bound, no flops to share), the
@@ -218,13 +219,10 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
   int live = comm_agree(comm, dist_s1_open(ctx, n));
   BK_TRY(live);
   void* pm = nullptr;
-  // strip (n x 64), Ysend (nb x 64), Yrecv (world x nb x 64), Y (n x 64)
-  BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_MISC, (2 * n * b + (int64_t)(world + 1) * nb * b) * sizeof(double), &pm)));
+  // strip (n x 64), Y (n x 64)
+  BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_MISC, 2 * n * b * sizeof(double), &pm)));
   double* sbuf = (double*)pm;
-  double* Ysend = sbuf + n * b;
-  double* Yrecv = Ysend + nb * b;
-  double* Y = Yrecv + (int64_t)world * nb * b;
-  BK_HIP(hipMemsetAsync(Ysend, 0, (size_t)(nb * b) * sizeof(double), st));
+  double* Y = sbuf + n * b;
   auto has_panel = [&](int64_t k) { return k + b < n && n - k - b > 1; };
   int status = BIGKRLS_OK;       // first local failure; collectives keep running
   auto local = [&](int rc) {
@@ -246,18 +244,11 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
     const int64_t la0 = std::min<int64_t>(std::max<int64_t>(k + b - c0, 0), ncl);   // first own column inside the trailing matrix
     const int64_t nact = ncl - la0;
     double* Aact = A + la0 * n + (k + b);
-    if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, Ysend + la0, nb));   // (waits for panel k's factorisation)
-    BK_TRY(comm_all_gather(comm, Ysend, Yrecv, nb * b));
-    if (status == BIGKRLS_OK) {
-      // rows k+b .. n of Y = A22 V from the ranks' blocks
-      for (int r = 0; r < world; ++r) {
-        const int64_t lo = std::max<int64_t>((int64_t)r * nb, k + b), hi = std::min<int64_t>((int64_t)(r + 1) * nb, n);
-        if (hi <= lo) continue;
-        local(copy_matrix(ctx, Yrecv + (int64_t)r * nb * b + (lo - (int64_t)r * nb), hi - lo, b, nb, Y + (lo - (k + b)), m));
-      }
-      local(dist_s1_thin(ctx, n, k, Y));
-    }
     const int64_t row0 = nact > 0 ? (c0 + la0) - (k + b) : 0;
+    // Y = A22 V as the sum over the ranks of A22[:, own columns] V[own rows]   (waits for panel k's factorisation)
+    if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, row0, Y, m));
+    BK_TRY(comm_all_reduce(comm, Y, m * b, COMM_SUM));
+    if (status == BIGKRLS_OK) local(dist_s1_thin(ctx, n, k, Y));
     const int64_t nxt = k + b;
     int64_t first = 0;                                   // own columns already updated before the look-ahead
     if (has_panel(nxt)) {

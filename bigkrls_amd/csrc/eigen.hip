@@ -2704,16 +2704,22 @@ static int dist_s1_wait_panel(bigkrls_ctx* ctx, DistS1* ds) {
   return BIGKRLS_OK;
 }
 
+// This rank's contribution to Y = A22 V (m x 64): A22[:, own columns] V[own rows, :] -- the plain N,N product along the
+// contiguous dimension of the column block (the transposed form A22[:, own]' V, which gives the own ROWS of Y, runs
+// at half the rate). The ranks' contributions are summed by an all-reduce of m x 64 doubles.
 int dist_s1_av(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* Acols, int64_t lda, int64_t ncols,
-               double* Yout, int64_t ldy) {
+               int64_t row0, double* Ypart, int64_t ldy) {
   DistS1* ds = nullptr;
   BK_TRY(dist_state(ctx, n, &ds));
   BK_TRY(dist_s1_wait_panel(ctx, ds));
   const int64_t m = n - k - S2_B;
-  BK_REQUIRE(m > 0 && ncols >= 0 && (ncols == 0 || (Acols && Yout && lda >= m && ldy >= ncols)), "s1_av: bad arguments");
-  if (ncols == 0) return BIGKRLS_OK;
-  // rows (own columns) of Y = A22 V: A22 is symmetric, so they are A22[:, own]' V
-  return gemm(ctx, 1, 0, ncols, S2_B, m, 1.0, Acols, lda, ds->ops.ws.Vp, m, 0.0, Yout, ldy);
+  BK_REQUIRE(m > 0 && ncols >= 0 && Ypart && ldy >= m && (ncols == 0 || (Acols && lda >= m && row0 >= 0 && row0 + ncols <= m)),
+             "s1_av: bad arguments");
+  if (ncols == 0) {
+    BK_HIP(hipMemsetAsync(Ypart, 0, (size_t)(ldy * S2_B) * sizeof(double), ctx->stream));
+    return BIGKRLS_OK;
+  }
+  return gemm(ctx, 0, 0, m, S2_B, ncols, 1.0, Acols, lda, ds->ops.ws.Vp + row0, m, 0.0, Ypart, ldy);
 }
 
 // the thin products of panel k from the gathered Y = A22 V: PZ1 = [V | Z], PZ2 = [Z | V]
