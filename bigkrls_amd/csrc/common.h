@@ -55,9 +55,6 @@ struct bigkrls_ctx {
   // set while a decomposition is retried after the watchdog of a persistent kernel fired: the
   // panel QR runs one launch per column and the bulge chasing one launch per wavefront
   bool no_resident = false;
-  // set while a decomposition is redone because pq_chol (CholeskyQR2 panel factorisation) left a panel unfactored:
-  // every panel then goes to the Householder kernel pq_resident
-  bool pq_householder = false;
   // state of a row-block distributed stage 1 between bigkrls_dev_s1_open and bigkrls_dev_eigen_resume
   void* dist_s1 = nullptr;
   void (*dist_s1_free)(void*) = nullptr;

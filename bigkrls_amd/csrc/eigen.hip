@@ -2452,41 +2452,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     {
       // watchdog word of the register-resident panel QR: checked before stage 2 consumes the band
       int h_err1 = 0;
-      double h_unfactored = 0.0;      // panels pq_chol left unfactored (and nobody factored: no pq_resident behind it)
-      PinnedFetch pf1(ctx, 2);
+      PinnedFetch pf1(ctx, 1);
       BK_TRY(pf1.add(&h_err1, s1.err, sizeof(int)));
-      if (s1.pqc) BK_TRY(pf1.add(&h_unfactored, s1.pqc + PQC_OFF_SLICES + PQC_NG + 32, sizeof(double)));
       BK_TRY(pf1.finish());
-      {
-        const char* pq_env = getenv("BIGKRLS_PQ");
-        if (pq_env && std::string(pq_env) == "pessimistic") h_unfactored = 0.0;   // (pq_resident did those panels)
-      }
-#ifdef BK_FAULT_INJECT
-      {
-        const char* fault0 = getenv("BIGKRLS_FAULT");   // BIGKRLS_FAULT=pqchol (test build): pretend pq_chol left a panel
-        if (fault0 && std::string(fault0) == "pqchol" && !ctx->pq_householder && !ctx->no_resident) h_unfactored = 1.0;
-      }
-#endif
-      if (h_unfactored > 0.0 && h_err1 == 0) {
-        if (getenv("BIGKRLS_VERBOSE"))
-          fprintf(stderr, "[bigkrls] eigen: pq_chol left %d panel(s) unfactored; redoing the decomposition with the "
-                          "Householder panel kernel\n", (int)h_unfactored);
-        if (mode == EIG_RESUME) {     // the distributed fit replays on every rank (with the per-step kernels)
-          set_error("eigen: the CholeskyQR2 panel factorisation left a panel unfactored during the distributed stage 1");
-          return BK_EWATCHDOG;
-        }
-        if (ctx->pq_householder) {
-          set_error("eigen: a panel was left unfactored although pq_chol was off");
-          return BIGKRLS_EHIP;
-        }
-        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamSynchronize(st);
-        ctx->pq_householder = true;
-        const int rc = eigen(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
-                             part_count, EIG_FULL);
-        ctx->pq_householder = false;
-        return rc;
-      }
 #ifdef BK_FAULT_INJECT
       // BIGKRLS_FAULT=watchdog (test build): pretend the watchdog fired on the first attempt
       const char* fault = getenv("BIGKRLS_FAULT");
@@ -2510,7 +2478,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     // built on the look-ahead stream from stage 1's output while the main stream goes on
     const char* bt1_env = getenv("BIGKRLS_BT1");
     const bool bt1_grouped = n_vecs_max > 0 && !(bt1_env && std::string(bt1_env) == "panel");
-    const int64_t LT1 = BT1_GRP * S2_B;
+    const int64_t LT1 = bt1_grp_for(n) * S2_B;
     double* bt1_G = nullptr;
     if (bt1_grouped) {
       bt1 = bt1_plan(n);
@@ -2622,10 +2590,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
                                    bt2_toff.empty() ? 0 : bt2_toff.back(), bt2_err));
       tick("back-transform stage 2");
       void* pw12 = nullptr;
-      BK_TRY(ws_get(ctx, SLOT_EIG_Z, (int64_t)2 * BT1_GRP * S2_B * pnv * sizeof(double), &pw12));
+      const int64_t bt1_w = (int64_t)bt1_grp_for(n) * S2_B;
+      BK_TRY(ws_get(ctx, SLOT_EIG_Z, 2 * bt1_w * pnv * sizeof(double), &pw12));
       if (bt1_V != nullptr)
         BK_TRY(back_transform_stage1_grouped(ctx, n, bt1, bt1_V, bt1_T, pvecs, ldv, pnv, (double*)pw12,
-                                             (double*)pw12 + (int64_t)BT1_GRP * S2_B * pnv));
+                                             (double*)pw12 + bt1_w * pnv));
       else
         BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
                                      (double*)pw12 + (int64_t)S2_B * pnv));
