@@ -2775,6 +2775,9 @@ int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int
 
 #ifdef BK_BC_PROF
 // profiling builds only (tools/bc_prof.py): the accumulated shader clocks of one bc_resident location per phase
+extern "C" int bigkrls_debug_bc_trace(unsigned long long* out, int count) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(bk::bc_trace), (size_t)count * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 extern "C" int bigkrls_debug_bc_prof(long long* out8, int reset) {
   if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(bk::bc_prof_acc), 8 * sizeof(long long)) != hipSuccess) return 1;
   if (out8) {   // slot 5 of the LDS-window kernel is unused: the column's send -> receipt time (10-ns ticks) travels there
