@@ -1549,8 +1549,8 @@ __global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
 // 4 MB L2 (BIGKRLS_KB_R overrides; a value >= the number of tile rows gives the plain column-by-column order)
 static int kb_band_rows(int64_t p, int tiles) {
   static const int r_env = [] { const char* e = getenv("BIGKRLS_KB_R"); return e ? atoi(e) : 0; }();
-  int64_t R = r_env > 0 ? r_env : (1 << 20) / (32 * 8 * std::max<int64_t>(p, 1));
-  R = std::max<int64_t>(8, std::min<int64_t>(R, 1024));
+  int64_t R = r_env > 0 ? r_env : std::max<int64_t>(8, (1 << 20) / (32 * 8 * std::max<int64_t>(p, 1)));
+  R = std::max<int64_t>(1, std::min<int64_t>(R, 1024));
   return (int)std::min<int64_t>(R, std::max(tiles, 1));
 }
 

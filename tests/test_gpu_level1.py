@@ -45,6 +45,19 @@ def test_gauss_kernel(lib, n, p):
     assert np.array_equal(out, out.T)          # bitwise symmetric like the reference's mirror
 
 
+@pytest.mark.parametrize("band_rows", [8, 5, 1])
+def test_kernel_builds_band_major_tile_order_with_several_bands(band_rows):
+    """The kernel builds' XCD-aware tile order with band heights of a few tile rows (the default, ~1 MB of X rows, gives a
+    single band at every size a CPU oracle reaches): tests/_kb_bands.py in a process of its own, every entry of
+    bGaussKernel / bTempKernel against the literal formula (src/gauss_kernel.cpp:13-30, src/temp_kernel.cpp:13-30)."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kb_bands.py"),
+                        str(band_rows)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "band-major tile maps OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_gauss_kernel_mtcars_golden(lib):
     """The reference's own golden vector (tests/testthat/test_basic_usage.R:71-108)."""
     import csv, os

@@ -25,6 +25,25 @@ PY
     rm -rf $O/pmc_kb_${tag}_$cnt
   done
 done
+# ---- round 4 extras: phase times, stage-2 profiles, MFMA utilisation ----------------------------------------------
+if [ -n "$R04_EXTRAS" ]; then
+  for cfg in "5000 10" "20000 20"; do
+    tag=$(echo $cfg | tr ' ' '_')
+    BIGKRLS_VERBOSE=1 python tools/eig_once.py $cfg > $O/eig_verbose_$tag.log 2>&1
+  done
+  if [ -f tools/libbigkrls_bcprof.so ]; then
+    BIGKRLS_BC_PROF_FLIGHT=1 python tools/bc_prof.py 20000 > $O/bc_prof_regwin.log 2>&1
+    BIGKRLS_BC=lds python tools/bc_prof.py 20000 > $O/bc_prof_lds.log 2>&1
+    python tools/bc_trace.py 20000 > $O/bc_trace.log 2>&1
+  fi
+  tools/pingpong > $O/pingpong.log 2>&1
+  tools/ic_read_probe 40 > $O/ic_read_probe.log 2>&1
+  CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmcA -o run -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcB -o run -- $CMD > /dev/null 2>&1
+  python tools/mfma_pmc.py $O/pmcA $O/pmcB $O/mfma_pmc_C3.json "$CMD" > $O/mfma_pmc_C3.log 2>&1
+  rm -rf $O/pmcA $O/pmcB
+fi
 if [ -n "$WITH_CPU" ]; then python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_C3_default_with_cpu_baseline.json; fi
 tail -3 $O/gpu_tests.log; cat $O/smoke.log | tail -2; cat $O/kernel_build_pmc.log; for f in $O/bench_*.json; do echo $f; python -c "
 import json,sys
