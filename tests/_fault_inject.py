@@ -40,6 +40,13 @@ again = ops.bEigen(K, 40, -1.0)
 assert rel(again.values, good.values) < 1e-12
 res, orth = quality(K, again.vectors, again.values)
 assert res < 1e-11 and orth < 1e-11, (res, orth)
+# BIGKRLS_FAULT=watchdog_bt2: the watchdog word of the persistent stage-2 back-transform reads as fired after the
+# decomposition: the call must redo it with per-wavefront launches
+os.environ["BIGKRLS_FAULT"] = "watchdog_bt2"
+third = ops.bEigen(K, 40, -1.0)
+assert rel(third.values, good.values) < 1e-12
+res, orth = quality(K, third.vectors, third.values)
+assert res < 1e-11 and orth < 1e-11, (res, orth)
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)

@@ -265,12 +265,14 @@ def test_eigen_is_run_to_run_deterministic(eig_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bc,pq", [("wavefront", "steps"), ("persistent", "steps"), ("resident", "resident")])
+@pytest.mark.parametrize("bc,pq", [("wavefront", "steps"), ("persistent", "steps"), ("resident", "resident"),
+                                   ("lds", "resident")])
 @pytest.mark.parametrize("n", [513, 1283])
 def test_eigen_two_stage_kernel_variants(lib, monkeypatch, bc, pq, n):
     """The fallback kernels of the two-stage path (one launch per bulge-chasing wavefront / per panel
     column, and the flag-synchronised persistent bulge chasing) must stay correct: they serve the
-    sizes the LDS- and register-resident kernels cannot (n > 32768, panels of > 80 workgroups)."""
+    sizes the location-resident kernels cannot (n > 32768, panels of > 80 workgroups); "resident" is the
+    register-window bulge chasing (bc_regwin, the default), "lds" the LDS-window kernel it replaced."""
     monkeypatch.delenv("BIGKRLS_EIG", raising=False)
     monkeypatch.setenv("BIGKRLS_BC", bc)
     if pq == "steps":
@@ -429,19 +431,24 @@ def test_eigen_divide_conquer_factored_top_levels(ctx, monkeypatch, kind, n, nei
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [700, 1283])
 def test_eigen_back_transform_variants(lib, monkeypatch, n):
-    """Back-transforms: the compact-WY MFMA kernel of stage 2 and the merged block reflectors of
-    stage 1 (defaults) against the reflector-by-reflector kernel (BIGKRLS_BT2=seq) and the
-    panel-by-panel loop (BIGKRLS_BT1=panel): same eigenvectors up to rounding."""
+    """Back-transforms: the compact-WY MFMA tasks of stage 2 in one persistent launch and the merged block
+    reflectors of stage 1 (defaults) against the reflector-by-reflector kernel (BIGKRLS_BT2=seq) and the
+    panel-by-panel loop (BIGKRLS_BT1=panel): same eigenvectors up to rounding; against the same tasks as one launch
+    per anti-diagonal (BIGKRLS_BT2=wavefront): bitwise."""
     monkeypatch.delenv("BIGKRLS_EIG", raising=False)
     X, y = orc.synth(n, 4, 23)
     K = orc.gauss_kernel_literal(X, 4.0)
     Kf = F(K)
     out = {}
-    for mode in ("wy", "seq"):
+    for mode in ("wy", "seq", "wavefront"):
         if mode == "seq":
             monkeypatch.setenv("BIGKRLS_BT2", "seq")
             monkeypatch.setenv("BIGKRLS_BT1", "panel")
             monkeypatch.setenv("BIGKRLS_S1", "gemm")      # stage 1's small products as separate GEMMs
+        elif mode == "wavefront":                          # the same compact-WY tasks, one launch per anti-diagonal
+            monkeypatch.setenv("BIGKRLS_BT2", "wavefront")
+            monkeypatch.delenv("BIGKRLS_BT1", raising=False)
+            monkeypatch.delenv("BIGKRLS_S1", raising=False)
         else:
             monkeypatch.delenv("BIGKRLS_BT2", raising=False)
             monkeypatch.delenv("BIGKRLS_BT1", raising=False)
@@ -453,6 +460,8 @@ def test_eigen_back_transform_variants(lib, monkeypatch, n):
         assert np.max(np.abs(K @ vecs - vecs * vals)) / vals[0] < 1e-11
         out[mode] = (vals, vecs)
     assert np.max(np.abs(out["wy"][0] - out["seq"][0])) / out["wy"][0][0] < 1e-13
+    # the persistent launch (ticket order) and the per-anti-diagonal launches run the same tasks on the same data
+    assert np.array_equal(out["wy"][0], out["wavefront"][0]) and np.array_equal(out["wy"][1], out["wavefront"][1])
     # well separated top of the spectrum: the vectors themselves agree
     assert np.max(np.abs(np.abs(out["wy"][1][:, :5]) - np.abs(out["seq"][1][:, :5]))) < 1e-9
 
