@@ -508,17 +508,19 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
             gbs = (by / 1e9) / (ms / 1e3)
             resident = ms * 1e3 / max(cnt, 1) > 1000.0   # one persistent launch per decomposition vs sampled ~10 us wavefront launches
             if resident:
-                return {"kernel": "bc_resident: LDS-resident bulge chasing (stage 2, band b=64 -> tridiagonal), one "
-                                  "persistent launch per fit, one workgroup per band location",
+                return {"kernel": "bc_regwin: location-resident bulge chasing (stage 2, band b=64 -> tridiagonal), one "
+                                  "persistent launch per fit, one 512-thread workgroup per band location with its 64 x 128 "
+                                  "window in registers (BIGKRLS_BC=lds: bc_resident, the window in LDS)",
                         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches": cnt, "avg_launch_us": round(ms * 1e3 / max(cnt, 1), 2),
                         "total_ms_per_fit": round(ms / args.steps, 2),
                         "avg_algorithmic_bytes_per_launch": round(by / max(cnt, 1), 0),
                         "note": "achieved = algorithmic HBM bytes (band read once, 16 N b, + stored reflectors, "
-                                "4 N^2) / HIP-event duration. The band lives in LDS for the whole stage; the kernel "
-                                "is bound by the 2 message hops per sweep between neighbouring workgroups and the "
-                                "phases between an arrival and the next send (N sweeps x ~3.7 us), not by HBM"}
+                                "4 N^2) / HIP-event duration. The band lives in registers for the whole stage; the kernel "
+                                "is bound by the 2 message hops per sweep between neighbouring workgroups (~0.9 us each) "
+                                "and the ~1.1 us the two locations compute between an arrival and their send (N sweeps x "
+                                "~3.1 us), not by HBM"}
             return {"kernel": "bc_wavefront: one anti-diagonal wavefront of bulge-chasing tasks (stage 2 of the "
                               "two-stage tridiagonalisation, band b=64 -> tridiagonal), ~2N launches per fit",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
