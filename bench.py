@@ -106,9 +106,11 @@ def symv_traffic(alg_bytes_total, launches):
 def pmc_ratio(kernel):
     """traffic / algorithmic HBM bytes of a kernel from the rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 correction and calibration as described in the files):
-    profiles/r03/r03_traffic_pmc.json (the trailing update in this round's tile order), then
+    profiles/r04/r04_traffic_pmc.json (the kernel build in round 4's tile order), profiles/r03/r03_traffic_pmc.json
+    (the trailing update in round 3's tile order), then
     profiles/r02/r02_traffic_pmc.json (A22 V), else profiles/r01_traffic_pmc.json; keys matched by prefix."""
-    for rel in (("profiles", "r03", "r03_traffic_pmc.json"), ("profiles", "r02", "r02_traffic_pmc.json"),
+    for rel in (("profiles", "r04", "r04_traffic_pmc.json"), ("profiles", "r03", "r03_traffic_pmc.json"),
+                ("profiles", "r02", "r02_traffic_pmc.json"),
                 ("profiles", "r01_traffic_pmc.json")):
         try:
             d = json.load(open(os.path.join(ROOT, *rel)))
