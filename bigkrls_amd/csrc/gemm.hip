@@ -1040,6 +1040,8 @@ __device__ __forceinline__ void band_major_rect(int64_t sq, int tiles_m, int til
   tm = r0 + (int)(sp % Rb);
 }
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 // Small-P variant (P <= 128: the fit's own regime, P = 5..50): the operands are a few
 // MB and live in L2, the output is 8 N^2 bytes, so the kernel is HBM-write bound and the
 // only job is to keep many independent store streams in flight. No LDS, no barriers:
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
     const double* __restrict__ A, int64_t lda, int U, const double* __restrict__ B, int64_t ldb, int V,
     int P, const double* __restrict__ na, const double* __restrict__ nb, double neg_inv_sigma,
     double* __restrict__ out, int64_t ldo, int64_t diag_shift, int tiles_m, int tiles_n, int band_rows,
-    int64_t ntiles) {
+    int nt_stores, int64_t ntiles) {
   __shared__ double etab[32];
   if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
   __syncthreads();
@@ -1149,7 +1151,14 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
           if (n < V) {
             double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
             if (mrow + 1 < U) {
-              *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
+              if (nt_stores) {                                  // (uniform; see kb_nontemporal)
+                d2v pr;
+                pr.x = lo;
+                pr.y = hi;
+                __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(dst));
+              } else {
+                *reinterpret_cast<double2*>(dst) = make_double2(lo, hi);
+              }
             } else if (mrow < U) {
               dst[0] = lo;
             }
@@ -1163,6 +1172,60 @@ __global__ __launch_bounds__(NT) void kernel_block_wave_kernel(
         }
       }
     }
+}
+
+// kb_store_tile with non-temporal stores
+template <bool CHECK>
+__device__ __forceinline__ void kbt_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
+                                               int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int lm = lane & 15, lk = lane >> 4;
+  const bool odd = (lane & 1) != 0;
+  if (!CHECK) {
+    double* base = out + (int64_t)(m0 + (lm & ~1)) + (int64_t)(n0 + lk + (odd ? 4 : 0)) * ldo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          d2v pr;
+          pr.x = odd ? recv : e[i][j][rp];
+          pr.y = odd ? e[i][j][rp + 1] : recv;
+          __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(base + i * 16 + (int64_t)(j * 16 + 4 * rp) * ldo));
+        }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int rp = 0; rp < 4; rp += 2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + lm;
+        if (vec_ok) {
+          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
+          const double recv = __shfl_xor(send, 1, 64);
+          d2v pr;
+          pr.x = odd ? recv : e[i][j][rp];
+          pr.y = odd ? e[i][j][rp + 1] : recv;
+          const int mrow = m & ~1;                              // first of the row pair
+          const int n = n0 + j * 16 + lk + 4 * (rp + (odd ? 1 : 0));
+          if (n < V) {
+            double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
+            if (mrow + 1 < U) __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(dst));
+            else if (mrow < U) __builtin_nontemporal_store(pr.x, dst);
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int n = n0 + j * 16 + lk + 4 * (rp + rr);
+            if (m < U && n < V) __builtin_nontemporal_store(e[i][j][rp + rr], out + (int64_t)m + (int64_t)n * ldo);
+          }
+        }
+      }
 }
 
 // Paired 16-byte stores of one wave's 32 x 32 tile held in MFMA accumulator layout
@@ -1229,7 +1292,8 @@ __device__ __forceinline__ void kb_store_tile(double* __restrict__ out, int64_t 
 template <int KS>
 __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
     const double* __restrict__ A, int64_t lda, int U, int P, const double* __restrict__ na,
-    double neg_inv_sigma, double* __restrict__ out, int64_t ldo, int tiles, int band_rows, int64_t ntiles) {
+    double neg_inv_sigma, double* __restrict__ out, int64_t ldo, int tiles, int band_rows, int nt_stores,
+    int64_t ntiles) {
   __shared__ double tbuf[4][32 * 33];
   __shared__ double etab[32];
   if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
@@ -1301,7 +1365,7 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
       }
     }
   const bool interior = vec_ok && m0 + 32 <= U && n0 + 32 <= U;     // (wave-uniform)
-  if (interior) kb_store_tile<false>(out, ldo, U, U, m0, n0, e, true);
+  if (interior) { if (nt_stores) kbt_store_tile<false>(out, ldo, U, U, m0, n0, e, true); else kb_store_tile<false>(out, ldo, U, U, m0, n0, e, true); }
   else kb_store_tile<true>(out, ldo, U, U, m0, n0, e, vec_ok);
   if (!diag_tile) {
     // transpose through LDS: E[mloc][nloc], then the mirrored tile's accumulator layout reads
@@ -1320,7 +1384,7 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) et[i][j][r] = tb[(j * 16 + lk + 4 * r) * 33 + (i * 16 + lm)];
-    if (interior) kb_store_tile<false>(out, ldo, U, U, n0, m0, et, true);
+    if (interior) { if (nt_stores) kbt_store_tile<false>(out, ldo, U, U, n0, m0, et, true); else kb_store_tile<false>(out, ldo, U, U, n0, m0, et, true); }
     else kb_store_tile<true>(out, ldo, U, U, n0, m0, et, vec_ok);
   }
 }
@@ -1339,62 +1403,6 @@ __global__ __launch_bounds__(NT) void kernel_block_sym_kernel(
 constexpr int KBT_KC = 32;            // columns of X staged per chunk
 constexpr int KBT_LD = 128 + 8;       // panel row stride in doubles (the k rows of a fragment read half the banks apart)
 constexpr size_t kbt_smem_bytes() { return (size_t)(2 * KBT_KC * KBT_LD + 256) * sizeof(double); }
-
-typedef double d2v __attribute__((ext_vector_type(2)));
-
-// kb_store_tile with non-temporal stores
-template <bool CHECK>
-__device__ __forceinline__ void kbt_store_tile(double* __restrict__ out, int64_t ldo, int U, int V,
-                                               int m0, int n0, const double (&e)[2][2][4], bool vec_ok) {
-  const int lane = threadIdx.x & 63;
-  const int lm = lane & 15, lk = lane >> 4;
-  const bool odd = (lane & 1) != 0;
-  if (!CHECK) {
-    double* base = out + (int64_t)(m0 + (lm & ~1)) + (int64_t)(n0 + lk + (odd ? 4 : 0)) * ldo;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int rp = 0; rp < 4; rp += 2)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
-          const double recv = __shfl_xor(send, 1, 64);
-          d2v pr;
-          pr.x = odd ? recv : e[i][j][rp];
-          pr.y = odd ? e[i][j][rp + 1] : recv;
-          __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(base + i * 16 + (int64_t)(j * 16 + 4 * rp) * ldo));
-        }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int rp = 0; rp < 4; rp += 2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + i * 16 + lm;
-        if (vec_ok) {
-          const double send = odd ? e[i][j][rp] : e[i][j][rp + 1];
-          const double recv = __shfl_xor(send, 1, 64);
-          d2v pr;
-          pr.x = odd ? recv : e[i][j][rp];
-          pr.y = odd ? e[i][j][rp + 1] : recv;
-          const int mrow = m & ~1;                              // first of the row pair
-          const int n = n0 + j * 16 + lk + 4 * (rp + (odd ? 1 : 0));
-          if (n < V) {
-            double* dst = out + (int64_t)mrow + (int64_t)n * ldo;
-            if (mrow + 1 < U) __builtin_nontemporal_store(pr, reinterpret_cast<d2v*>(dst));
-            else if (mrow < U) __builtin_nontemporal_store(pr.x, dst);
-          }
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            const int n = n0 + j * 16 + lk + 4 * (rp + rr);
-            if (m < U && n < V) __builtin_nontemporal_store(e[i][j][rp + rr], out + (int64_t)m + (int64_t)n * ldo);
-          }
-        }
-      }
-}
 
 template <bool SYM>
 __global__ __launch_bounds__(NT, 2) void kernel_block_tiled_kernel(
@@ -1554,6 +1562,17 @@ static int kb_band_rows(int64_t p, int tiles) {
   return (int)std::min<int64_t>(R, std::max(tiles, 1));
 }
 
+// Non-temporal stores of the output tiles (the wave kernels; the workgroup-tiled kernel always uses them): the 8 N^2
+// bytes of K pass through the write-back L2s and evict the rows of X the tiles are built from. While X fits an XCD's
+// 4 MB L2 beside the output stream that costs nothing and ordinary stores are 6 % faster (N = 20 000, P = 20: 0.730 vs
+// 0.775 ms); above, the re-fetches stall the waves and non-temporal stores are 13 % faster (N = 50 000: 4.80 -> 4.24 ms,
+// 4.17 -> 4.71 TB/s written). BIGKRLS_KB_NT=0|1 overrides.
+static int kb_nontemporal(int64_t rows, int64_t p) {
+  static const int env = [] { const char* e = getenv("BIGKRLS_KB_NT"); return e ? atoi(e) : -1; }();
+  if (env >= 0) return env != 0;
+  return rows * p * (int64_t)sizeof(double) > (7ll << 19);    // 3.5 MB
+}
+
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift) {
@@ -1624,9 +1643,10 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
     BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
     const dim3 grid((unsigned)((ntiles + 3) / 4));
     const int band_rows = kb_band_rows(p, tiles);
+    const int kb_nt = kb_nontemporal(u, p);
 #define BK_KBS(KS)                                                                                 \
   hipLaunchKernelGGL(kernel_block_sym_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u,   \
-                     (int)p, (const double*)pna, -1.0 / sigma, out, ldo, tiles, band_rows, ntiles)
+                     (int)p, (const double*)pna, -1.0 / sigma, out, ldo, tiles, band_rows, kb_nt, ntiles)
     switch (ks) {
       case 1: BK_KBS(1); break;
       case 2: BK_KBS(2); break;
@@ -1652,10 +1672,11 @@ int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, cons
     BK_REQUIRE((ntiles + 3) / 4 < (1ll << 31), "kernel_block: too many tiles");
     const dim3 grid((unsigned)((ntiles + 3) / 4));
     const int band_rows = kb_band_rows(p, tiles_m);
+    const int kb_nt = kb_nontemporal(std::max(u, v), p);
 #define BK_KBW(KS)                                                                                  \
   hipLaunchKernelGGL(kernel_block_wave_kernel<KS>, grid, dim3(NT), 0, ctx->stream, A, lda, (int)u, B, \
                      ldb, (int)v, (int)p, (const double*)pna, (const double*)pnb, -1.0 / sigma, out,  \
-                     ldo, diag_shift, tiles_m, tiles_n, band_rows, ntiles)
+                     ldo, diag_shift, tiles_m, tiles_n, band_rows, kb_nt, ntiles)
     switch (ks) {
       case 1: BK_KBW(1); break;
       case 2: BK_KBW(2); break;
