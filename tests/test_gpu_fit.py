@@ -411,13 +411,19 @@ def test_dist_paths_under_a_world1_rccl_group(ctx):
 
 
 @pytest.mark.gpu
-def test_two_contexts_fit_concurrently_on_one_gpu():
+@pytest.mark.parametrize("bt2", ["default", "chain"])
+def test_two_contexts_fit_concurrently_on_one_gpu(monkeypatch, bt2):
     """Two contexts with their own streams on one device, one host thread each, fitting at the same
     time (include/bigkrls.h "Threading": one context per thread). n = 5000: the persistent kernels of
     both decompositions (24 + 79 workgroups each) are co-resident. Results must be bitwise those of the
-    same fits run one after the other."""
+    same fits run one after the other. `chain`: the stage-2 back-transform as chains of tasks (the default only
+    above n = 8000), whose ticket scheme must not need co-residency either."""
     import threading
     import bigkrls_amd as bk
+    if bt2 == "chain":
+        monkeypatch.setenv("BIGKRLS_BT2", "chain")
+    else:
+        monkeypatch.delenv("BIGKRLS_BT2", raising=False)
     data = [orc.synth(5000, 6, 60 + i) for i in range(2)]
     ctxs = [bk.Context(0, own_stream=True) for _ in range(2)]
     seq = [bk.bigKRLS(y, X, ctx=c) for (X, y), c in zip(data, ctxs)]

@@ -434,14 +434,21 @@ def test_eigen_back_transform_variants(lib, monkeypatch, n):
     """Back-transforms: the compact-WY MFMA tasks of stage 2 in one persistent launch and the merged block
     reflectors of stage 1 (defaults) against the reflector-by-reflector kernel (BIGKRLS_BT2=seq) and the
     panel-by-panel loop (BIGKRLS_BT1=panel): same eigenvectors up to rounding; against the same tasks as one launch
-    per anti-diagonal (BIGKRLS_BT2=wavefront): bitwise."""
+    per anti-diagonal (BIGKRLS_BT2=wavefront) and as chains of tasks (BIGKRLS_BT2=chain): bitwise."""
     monkeypatch.delenv("BIGKRLS_EIG", raising=False)
     X, y = orc.synth(n, 4, 23)
     K = orc.gauss_kernel_literal(X, 4.0)
     Kf = F(K)
     out = {}
-    for mode in ("wy", "seq", "wavefront"):
-        if mode == "seq":
+    for mode in ("wy", "seq", "wavefront", "chain", "chain3"):
+        monkeypatch.delenv("BIGKRLS_BT2_SEG", raising=False)
+        if mode in ("chain", "chain3"):                    # chains along the sweep groups (the default above n = 8000)
+            monkeypatch.setenv("BIGKRLS_BT2", "chain")
+            if mode == "chain3":                           # three groups per ticket: every rotation of the LDS window,
+                monkeypatch.setenv("BIGKRLS_BT2_SEG", "3") # segment ends inside and at the end of the chains
+            monkeypatch.delenv("BIGKRLS_BT1", raising=False)
+            monkeypatch.delenv("BIGKRLS_S1", raising=False)
+        elif mode == "seq":
             monkeypatch.setenv("BIGKRLS_BT2", "seq")
             monkeypatch.setenv("BIGKRLS_BT1", "panel")
             monkeypatch.setenv("BIGKRLS_S1", "gemm")      # stage 1's small products as separate GEMMs
@@ -462,6 +469,9 @@ def test_eigen_back_transform_variants(lib, monkeypatch, n):
     assert np.max(np.abs(out["wy"][0] - out["seq"][0])) / out["wy"][0][0] < 1e-13
     # the persistent launch (ticket order) and the per-anti-diagonal launches run the same tasks on the same data
     assert np.array_equal(out["wy"][0], out["wavefront"][0]) and np.array_equal(out["wy"][1], out["wavefront"][1])
+    # ... and so do the chains, which keep the rows two consecutive tasks share in LDS
+    for mode in ("chain", "chain3"):
+        assert np.array_equal(out["wy"][1], out[mode][1]), mode
     # well separated top of the spectrum: the vectors themselves agree
     assert np.max(np.abs(np.abs(out["wy"][1][:, :5]) - np.abs(out["seq"][1][:, :5]))) < 1e-9
 
