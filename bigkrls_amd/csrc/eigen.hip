@@ -668,16 +668,17 @@ __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ 
   if (j < K - 1) {
     const double dj = dl[j], dj1 = dl[j + 1];
     const double half = 0.5 * (dj1 - dj);
-    double g = 0.0, rl = 0.0, rr = 0.0;
+    // value at the midpoint, split into the poles below and above ((dj1 - dl_i) - half = -((dl_i - dj) - half): one
+    // reciprocal per term serves all three sums)
+    double rl = 0.0, rr = 0.0;
     for (int i = lane; i < K; i += 64) {
-      const double w2 = ww[i] * ww[i];
-      g += w2 / ((dl[i] - dj) - half);
-      if (i > j) rr += w2 / ((dl[i] - dj) - half);
-      else rl += w2 / ((dj1 - dl[i]) - half);
+      const double t = ww[i] * ww[i] * rcp_fast((dl[i] - dj) - half);
+      if (i > j) rr += t;
+      else rl -= t;
     }
-    g = 1.0 + rho * wsum(g);
     rr = wsum(rr);
     rl = wsum(rl);
+    const double g = 1.0 + rho * (rr - rl);
     hi = half;
     if (g >= 0.0) {
       org = j; sgn = 1.0;
@@ -699,6 +700,9 @@ __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ 
   lo = fmin(lo, hi) * (1.0 - 8.0 * DEPS);
   if (!(lo > 0.0)) lo = hi * 1e-300;
   const double dorg = dl[org];
+  // the two poles next to the root, measured from the origin (one of them is 0); the last root has no upper pole
+  const bool two_poles = j < K - 1;
+  const double pa = two_poles ? dl[j] - dorg : 0.0, pb = two_poles ? dl[j + 1] - dorg : 0.0;
   // Safeguarded Newton inside the bracket [lo, hi] (in |tau|): every evaluation yields f, f' and
   // the sum of absolute terms (the rounding-error scale of f); the bracket is updated from the
   // sign of f, the Newton step is taken when it stays strictly inside the bracket and otherwise
@@ -709,23 +713,42 @@ __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ 
   for (int it = 0; it < 200; ++it) {
     if (!(hi > lo) || !(x > lo) || !(x < hi)) break;
     const double tau = sgn * x;
-    double g = 0.0, gp = 0.0, ga = 0.0;
+    // psi: the poles up to j (terms < 0), phi: the poles above (terms > 0); derivatives likewise
+    double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
     for (int i = lane; i < K; i += 64) {
       const double inv = rcp_fast((dl[i] - dorg) - tau);
       const double t = ww[i] * ww[i] * inv;
-      g += t;
-      gp += t * inv;
-      ga += fabs(t);
+      if (i > j) { phi += t; dphi += t * inv; }
+      else       { psi += t; dpsi += t * inv; }
     }
-    g = 1.0 + rho * wsum(g);
-    gp = rho * wsum(gp);          // df/dtau > 0
-    ga = 1.0 + rho * wsum(ga);
+    psi = wsum(psi); phi = wsum(phi); dpsi = rho * wsum(dpsi); dphi = rho * wsum(dphi);
+    const double g = 1.0 + rho * (psi + phi);
+    const double gp = dpsi + dphi;                      // df/dtau > 0
+    const double ga = 1.0 + rho * (phi - psi);          // sum of the absolute terms
     const bool pos = (g >= 0.0);
     if (sgn > 0.0) { if (pos) hi = x; else lo = x; }
     else           { if (pos) lo = x; else hi = x; }
     if (fabs(g) <= 8.0 * DEPS * ga) { lo = x; hi = x; break; }
-    // Newton in tau = sgn * x:  tau_new = tau - g / gp
-    const double xn = sgn * (tau - g / gp);
+    // Step: psi and phi are each replaced by s + a / (pole - tau) through the nearest pole below / above with the
+    // value and slope they have here (the "middle way" of Li 1994, the scheme of LAPACK's dlaed4): the resulting
+    // quadratic in the increment eta is solved in the form that does not cancel. A plain Newton step in tau where
+    // that is not available (last root) or leaves the bracket; the (geometric) midpoint when Newton leaves it too.
+    double xn = sgn * (tau - g / gp);
+    if (two_poles) {
+      const double DA = pa - tau, DB = pb - tau;         // < 0 < (inside the interval)
+      const double c = g - DA * dpsi - DB * dphi;
+      const double a = (DA + DB) * g - DA * DB * gp;
+      const double b = DA * DB * g;
+      double eta;
+      if (c == 0.0) {
+        eta = b / a;
+      } else {
+        const double disc = sqrt(fabs(a * a - 4.0 * b * c));
+        eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+      }
+      const double xr = sgn * (tau + eta);
+      if (g * eta < 0.0 && xr > lo && xr < hi) xn = xr;  // (f increases: the step must go against the sign of f)
+    }
     const double mid = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
     x = (xn > lo && xn < hi) ? xn : mid;
   }
@@ -756,7 +779,7 @@ __global__ __launch_bounds__(256) void dc_zhat(const MergeDesc* __restrict__ des
   double p = 1.0;
   for (int j = lane; j < K; j += 64) {
     const double delta = (di - dorg[base + j]) - tau[base + j];
-    p *= (j == i) ? delta : delta / (di - dlam[base + j]);
+    p *= (j == i) ? delta : delta * rcp_fast(di - dlam[base + j]);
   }
   p = wprod(p);
   if (lane == 0) zhat[base + r] = copysign(sqrt(fabs(p)), w[base + i]);
