@@ -240,6 +240,12 @@ def _visible_gpus():
         return 0
 
 
+def _share_gpu():
+    """BIGKRLS_BENCH_SHARE_GPU=1 (tests only, with BIGKRLS_RCCL_LIB = tests/mock_rccl): all ranks on device 0, gloo for
+    this program's own barrier -- the launcher, the rank processes and the library's RCCL code path on a 1-GPU box."""
+    return os.environ.get("BIGKRLS_BENCH_SHARE_GPU") == "1"
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) outside a launcher: this process starts the N ranks itself -- the reference's
     parallel path also starts its own workers (R/bigKRLS.R:340-343, makeCluster(Ncores)) -- as N children of THIS
@@ -247,7 +253,7 @@ def launch_ranks(args):
     JSON line as its last line of stdout and exits non-zero if any rank fails. It never touches the GPU and never
     re-executes itself. Fewer visible devices than N is an error, not a silent one-GPU run."""
     n = args.gpus
-    if not args.dry_launch:
+    if not args.dry_launch and not _share_gpu():
         have = _visible_gpus()
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible "
@@ -363,6 +369,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    share = world > 1 and _share_gpu()
+    if share:
+        local_rank = 0
     if world > 1 and torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)",
               file=sys.stderr)
@@ -372,8 +381,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29571")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
 
@@ -419,7 +431,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     if world > 1 or args.force_dist:
         from bigkrls_amd import dist as bkdist
 
-        comm = bkdist.get_comm(ctx)
+        comm = bkdist.get_comm(ctx, "rccl")               # the library's own RCCL communicator, whatever torch's group is
         comm_rank, comm_nranks = comm.rank_count()        # read back from the library's rank object (bigkrls_comm_rank)
         if (comm_rank, comm_nranks) != (rank, world):
             raise RuntimeError(f"communicator says rank {comm_rank} of {comm_nranks}, launcher says {rank} of {world}")
@@ -456,7 +468,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else ctx.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     sec_per_fit = dt / args.steps

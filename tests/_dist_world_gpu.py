@@ -7,7 +7,12 @@ rank is its own process with its own context on device 0, the collectives stage 
 memory and a gloo group (bigkrls_amd.dist.comm_callbacks; test only, the product path uses RCCL).
 Checks every rank's result -- and its column blocks of K and vcov.est.c -- against the single-process fit.
 
-    python tests/_dist_world_gpu.py [N] [P] [WORLD] [--krylov NEIG]
+    python tests/_dist_world_gpu.py [N] [P] [WORLD] [--krylov NEIG] [--rccl-mock]
+
+--rccl-mock: the communicator is built the way the product builds it -- bigkrls_comm_unique_id on rank 0, the id
+broadcast over the process group, bigkrls_comm_create: csrc/dist.hip's dlopen'd function table and its stream-ordered,
+asynchronous collectives -- with BIGKRLS_RCCL_LIB pointing at tests/mock_rccl/libmock_rccl.so, a stand-in for librccl
+that accepts several ranks on one device (shared memory between the rank processes, same stream semantics).
 
 The launcher never touches the GPU: it only starts the rank processes. tests/conftest.py starts the launchers at
 session start (before the pytest process itself initialises the GPU) and tests/test_gpu_dist_world.py collects them.
@@ -71,10 +76,18 @@ def worker():
         L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "libbigkrls_hip_fault.so")
         if rank == fault_rank:
             os.environ["BIGKRLS_FAULT"] = "s1_open"
+    mock = "--rccl-mock" in sys.argv
+    if mock:
+        os.environ["BIGKRLS_RCCL_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock_rccl", "libmock_rccl.so")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = bk.Context(0)
-    comm = bkdist.get_comm(ctx, "host")                   # bigkrls_comm_create_callbacks: collectives staged through gloo
-    assert (comm.world, comm.rank, comm.kind) == (world, rank, "callbacks")
+    if mock:
+        comm = bkdist.get_comm(ctx, "rccl")               # bigkrls_comm_unique_id / bigkrls_comm_create: the product's path
+        assert (comm.world, comm.rank, comm.kind) == (world, rank, "rccl")
+        assert comm.rank_count() == (rank, world)
+    else:
+        comm = bkdist.get_comm(ctx, "host")               # bigkrls_comm_create_callbacks: collectives staged through gloo
+        assert (comm.world, comm.rank, comm.kind) == (world, rank, "callbacks")
     X, y = synth(n, p, 103)
     kw = dict(Neig=neig) if neig else {}
     if trunc is not None:

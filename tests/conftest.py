@@ -24,6 +24,19 @@ WORLD_CASES = {
     "dense_world2_rank_failure": ["600", "4", "2", "--eigtrunc", "0.001", "--fault-rank", "1"],                # n <= 256: K gathered, Q by all-reduce
     # ONE rank's persistent-kernel watchdog fires (test build): agreed on by all ranks, decomposition replayed everywhere
     "dense_world2_watchdog_replay": ["900", "4", "2", "--eigtrunc", "0.001", "--watchdog-rank", "1"],
+    # The product's own communicator path (unique id -> bigkrls_comm_create -> the dlopen'd function table, collectives
+    # asynchronous on the context's stream) over tests/mock_rccl, with the library's DEFAULT kernels ("--default-knobs":
+    # the persistent panel factorisation / bulge chasing beside the collectives; a watchdog that fires because the rank
+    # processes of this session crowd one GPU is agreed on and replayed)
+    "rccl_mock_dense_world2": ["3000", "8", "2", "--rccl-mock", "--default-knobs"],
+    "rccl_mock_dense_world3_ragged": ["2500", "6", "3", "--rccl-mock"],
+    "rccl_mock_krylov_world2": ["17000", "10", "2", "--krylov", "60", "--rccl-mock", "--default-knobs"],
+    "rccl_mock_dense_world4_empty_rank": ["300", "4", "4", "--eigtrunc", "0.001", "--rccl-mock"],
+}
+# `python bench.py --gpus 2` end to end on the one GPU: its own launcher, two rank processes, the library's RCCL
+# communicator over tests/mock_rccl (BIGKRLS_BENCH_SHARE_GPU=1: both ranks on device 0, gloo for the program's barrier)
+BENCH_CASES = {
+    "bench_gpus2_c2": ["--gpus", "2", "--config", "C2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
 }
 _world_runs = {}
 
@@ -45,11 +58,24 @@ def pytest_sessionstart(session):
     import tempfile
     for name, args in WORLD_CASES.items():
         log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
-        # Seven rank processes share the one GPU with this session: the persistent kernels of the eigensolver spin on
-        # messages between workgroups that must be co-resident, which nothing guarantees here, and a fired watchdog
-        # cannot be replayed in the partitioned stage 1 -- the rank processes use the launch-per-step kernels.
+        # Some thirty rank processes share the one GPU with this session: the persistent kernels of the eigensolver spin
+        # on messages between workgroups that must be co-resident, which nothing guarantees here -- most cases use the
+        # launch-per-step kernels (a fired watchdog is replayed, but each replay costs seconds); "--default-knobs"
+        # cases run the library as shipped.
         env = dict(os.environ, BIGKRLS_PQ="steps", BIGKRLS_BC="wavefront")
+        if "--default-knobs" in args:
+            env = dict(os.environ)
         proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_world_gpu.py")] + args,
+                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env)
+        _world_runs[name] = (proc, log.name)
+
+
+    for name, args in BENCH_CASES.items():
+        log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
+        env = dict(os.environ, BIGKRLS_BENCH_SHARE_GPU="1",
+                   BIGKRLS_RCCL_LIB=os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so"))
+        env.pop("WORLD_SIZE", None)
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args,
                                 stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env)
         _world_runs[name] = (proc, log.name)
 

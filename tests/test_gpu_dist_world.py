@@ -2,11 +2,15 @@
 (tests/_dist_world_gpu.py): the partitioned dense stage 1 with column-block offsets (a ragged last block, a rank
 that owns nothing), the split back-transform, the sharded block Lanczos, the replicated decomposition of a tiny
 problem, the row-block lambda search; every rank compared with the single-process fit of the same data. The rank
-processes are started by conftest.py at session start; RCCL itself is covered at world size 1 (test_gpu_fit.py)
-because it refuses two ranks on one device."""
+processes are started by conftest.py at session start. RCCL itself refuses two ranks on one device: it is covered
+at world size 1 (test_gpu_fit.py), and the library's RCCL code path -- unique id, bigkrls_comm_create, the dlopen'd
+function table, collectives asynchronous on the context's stream, default kernels -- at world sizes 2-4 over
+tests/mock_rccl (the "rccl_mock_*" cases and `bench.py --gpus 2`)."""
 import pytest
 
-from conftest import WORLD_CASES
+import json
+
+from conftest import BENCH_CASES, WORLD_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -29,3 +33,25 @@ def test_world_n_hip_backend_matches_single_fit(world_runs, name):
     if name.endswith("watchdog_replay"):
         # the fault fired in ONE rank; every rank must have replayed (the decision is agreed, not local)
         assert text.count("replaying the distributed decomposition") == world, text[-4000:]
+
+
+@pytest.mark.parametrize("name", sorted(BENCH_CASES))
+def test_bench_gpus2_through_the_rccl_path(world_runs, name):
+    """`python bench.py --gpus 2`: the launcher starts two ranks, each builds the library's RCCL communicator
+    (bigkrls_comm_unique_id / bigkrls_comm_create; librccl replaced by tests/mock_rccl, which accepts two ranks on one
+    device and keeps the stream-ordered semantics) and runs bigkrls_fit_dist with the default kernels; the last line
+    of stdout is rank 0's JSON line with n_gpus = 2 and the rank count read back from the library."""
+    if name not in world_runs:
+        pytest.skip("rank processes were not started (no GPU at session start)")
+    proc, log = world_runs[name]
+    try:
+        rc = proc.wait(timeout=900)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    text = open(log).read()
+    assert rc == 0, text[-4000:]
+    line = [ln for ln in text.splitlines() if ln.lstrip().startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["comm_nranks"] == 2 and res["scaling"] == "strong", line[:400]
+    assert res["value"] > 0 and "N=5000" in res["config"]["workload"], line[:400]
