@@ -65,7 +65,7 @@ def parse():
                     help="comma-separated 1-based columns, e.g. 1,3,5")
     ap.add_argument("--cpu-n", type=int, default=None,
                     help="rows of the CPU-baseline sample (default: the bench N for C2/C3)")
-    ap.add_argument("--cpu-budget-s", type=float, default=900.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=700.0,
                     help="wall-clock bound of the CPU baseline; what is measured until then is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -130,7 +130,7 @@ class CpuBaseline:
     done or the budget is spent (then the child, this exact PID, is killed) and assembles the
     `cpu_baseline` object from the phases measured until then."""
 
-    def __init__(self, n, p, seed, eigtrunc, small_n=2000, budget_s=900.0):
+    def __init__(self, n, p, seed, eigtrunc, small_n=2000, budget_s=700.0):
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--p", str(p),
                "--seed", str(seed), "--small-n", str(small_n), "--budget-s", str(budget_s)]
         if eigtrunc is not None:

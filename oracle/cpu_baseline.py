@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--eigtrunc", type=float, default=None)
     ap.add_argument("--small-n", type=int, default=2000)
     ap.add_argument("--probes", type=int, default=6, help="literal solveforc probes timed in full")
-    ap.add_argument("--budget-s", type=float, default=900.0,
+    ap.add_argument("--budget-s", type=float, default=700.0,
                     help="wall-clock the parent allows: literal derivative columns are timed in full while they fit")
     ap.add_argument("--no-wait", action="store_true")
     args = ap.parse_args()
