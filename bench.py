@@ -474,7 +474,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
     sec_per_fit = dt / args.steps
 
     prof = {name: ctx.get_profile(name) for name in
-            ("symv", "kernel_block", "trailing_update", "band_update", "band_update2", "band_av", "bulge_chase",
+            ("symv", "kernel_block", "trailing_update", "band_update", "band_update2", "band_update4", "band_av", "bulge_chase",
              "panel_qr", "lanczos_kb", "lanczos_cgs2", "solveforc_probe", "deriv_rows", "yhat_gemv", "vcov_syrk")}
     ctx.set_profile(False)
 
@@ -497,7 +497,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                     "total_ms_per_fit": round(ms * stride / args.steps, 2),
                     "avg_algorithmic_flops_per_launch": round(fl / max(cnt, 1), 0),
                     "note": note + ("; every 8th panel is bracketed (total_ms_per_fit = 8 x the sampled time)"
-                                    if stride > 1 else "")}
+                                    if stride == STRIDE else "")}
 
         def symv_entry():
             ms, by, cnt = prof["symv"]
@@ -628,13 +628,21 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        if pmc_ratio("syrk_mirror_kernel<64> k=128") else None),
             mfma_entry("band_update2", "syrk_mirror_kernel<64> at k = 256: A22 -= [V Z V Z][Z V Z V]' for a GROUP of two "
                        "panels, applied as two pieces of equal area (the columns right / left of a cut), one per panel "
-                       "step, each concurrent with the next panel's QR (stage 1 while the trailing matrix has >= 12288 rows)",
+                       "step, each concurrent with the next panel's QR (stage 1 while the trailing matrix has 10752 .. 12800 rows)",
                        "achieved = algorithmic flops of the piece's columns of the lower triangle, 2*256*sum_c (m - c), / "
                        "HIP-event duration on the launch stream; traffic = algorithmic HBM bytes of the piece (read 4 + write 8 "
                        "bytes per lower-triangle entry, mirrored: 12 bytes per 256 flops) x the FETCH_SIZE+WRITE_SIZE / "
                        "algorithmic ratio measured for the two pieces (profiles/r03/r03_traffic_pmc.json, 1.014)",
                        traffic=(lambda flops: round(12.0 * flops / 256.0 * pmc_ratio("syrk_mirror_kernel<64> k=256, the two"), 0))
                        if pmc_ratio("syrk_mirror_kernel<64> k=256, the two") else None),
+            mfma_entry("band_update4", "syrk_mirror_kernel<64> at k = 512: A22 -= U U'^T for a GROUP of four panels, the "
+                       "whole lower tile triangle in one launch at the end of the group's fourth step, concurrent with the "
+                       "next panel's factorisation (stage 1 while the trailing matrix has >= 12800 rows)",
+                       "achieved = 512 m^2 algorithmic flops per launch (lower triangle) / HIP-event duration on the launch "
+                       "stream, every second group bracketed (total_ms_per_fit = 2 x the sampled time); traffic = algorithmic "
+                       "HBM bytes (12 bytes per 512 flops) x the whole-triangle k = 512 ratio of profiles/r03/r03b_syrk_traffic_pmc.json (1.145)",
+                       traffic=(lambda flops: round(12.0 * flops / 512.0 * 1.145, 0)),
+                       stride=2),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
                        "achieved = 2 m^2 b flops per launch (b = 64) / HIP-event duration; traffic = algorithmic HBM bytes of "
                        "the launch (A22 read once, 8 m^2, + V and Y, 16 m b: 1/16 byte per flop) x the ratio of "
@@ -655,16 +663,15 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
         # The two trailing-update entries are launches of ONE kernel (syrk_mirror_kernel<64>, one row in a rocprofv3
         # listing) at two ranks: it competes for "dominant kernel" with its total time, at its blended rate.
         upd = [c for c in cands if c["kernel"].startswith("syrk_mirror_kernel")]
-        if len(upd) == 2:
-            u1, u2 = upd
+        if len(upd) >= 2:
             ms = [c["total_ms_per_fit"] for c in upd]
             fl = [c["achieved"] * c["total_ms_per_fit"] for c in upd]          # TFLOP/s x ms
             ln = [c["launches_sampled"] for c in upd]
             tf = sum(fl) / sum(ms)
             tr = ([c["traffic"] * c["launches_sampled"] for c in upd] if all(c["traffic"] for c in upd) else None)
             merged = {"kernel": "syrk_mirror_kernel<64>: the stage-1 trailing update A22 -= [V Z][Z V]' (lower tile "
-                                "triangle + mirrored store), k = 256 pieces for groups of two panels while the trailing "
-                                "matrix has >= 14848 rows, k = 128 per panel below",
+                                "triangle + mirrored store): k = 512 for groups of four panels while the trailing matrix "
+                                "has >= 12800 rows, k = 256 pieces for groups of two down to 10752, k = 128 per panel below",
                       "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
                       "traffic": round(sum(tr) / sum(ln), 0) if tr else None,
@@ -673,8 +680,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                       "total_ms_per_fit": round(sum(ms), 2),
                       "avg_algorithmic_flops_per_launch": round(
                           sum(c["avg_algorithmic_flops_per_launch"] * c["launches_sampled"] for c in upd) / sum(ln), 0),
-                      "note": "time-weighted over the kernel's two launch shapes (see `parts`); achieved = algorithmic "
-                              "flops / HIP-event duration on the launch stream, every 8th panel bracketed; traffic = "
+                      "note": "time-weighted over the kernel's launch shapes (see `parts`); achieved = algorithmic "
+                              "flops / HIP-event duration on the launch stream, sampled launches (see the parts); traffic = "
                               "launch-weighted mean of the parts' figures",
                       "parts": upd}
             cands = [c for c in cands if c not in upd] + [merged]

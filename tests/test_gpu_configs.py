@@ -502,11 +502,12 @@ def test_lanczos_sampled_verification_matches_full_rayleigh_ritz(ctx, monkeypatc
 
 
 def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatch):
-    """Stage 1 above 10752 trailing rows applies the trailing update for two panels at once (k = 256),
-    as two pieces of equal area with thin corrections of everything that reads the stale matrix
-    (csrc/eigen_2stage.inc, "aggregated phase"). n = 15700 runs a few groups of it plus the hand-over to
-    one update per panel; BIGKRLS_S1AGG=0 is the plain loop. Same eigenvalues to rounding, kept
-    eigenvectors with residual and orthogonality at rounding level."""
+    """Stage 1 applies the trailing update for four panels at once (k = 512) while the trailing matrix has at least
+    12800 rows, for two at once (k = 256, as two pieces of equal area) down to 10752, with thin corrections of
+    everything that reads the stale matrix (csrc/eigen_2stage.inc, "aggregated phase"). n = 15700 runs ten groups
+    of four, the hand-over to pairs and the one to one update per panel; BIGKRLS_S1AGG=2 starts with pairs,
+    BIGKRLS_S1AGG=0 is the plain loop. Same eigenvalues to rounding, kept eigenvectors with residual and
+    orthogonality at rounding level."""
     from bigkrls_amd import ops
     from bigkrls_amd.synth import synth
     n, p = 15700, 7
@@ -517,10 +518,14 @@ def test_aggregated_trailing_update_matches_one_update_per_panel(ctx, monkeypatc
     plain = ops.bEigen(K, None, 0.001)
     monkeypatch.delenv("BIGKRLS_S1AGG")
     agg = ops.bEigen(K, None, 0.001)
-    assert agg.lastkeeper == plain.lastkeeper
-    assert rel(agg.values, plain.values) < 1e-13
-    res, orth = eigen_quality(ops, K, agg.vectors, agg.values)
-    assert res < 1e-11 and orth < 1e-11 and abs(agg.values.sum() - n) < 1e-11 * n
+    monkeypatch.setenv("BIGKRLS_S1AGG", "2")
+    pairs = ops.bEigen(K, None, 0.001)
+    monkeypatch.delenv("BIGKRLS_S1AGG")
+    for dec in (agg, pairs):
+        assert dec.lastkeeper == plain.lastkeeper
+        assert rel(dec.values, plain.values) < 1e-13
+        res, orth = eigen_quality(ops, K, dec.vectors, dec.values)
+        assert res < 1e-11 and orth < 1e-11 and abs(dec.values.sum() - n) < 1e-11 * n
 
 
 def test_panel_factorisation_by_choleskyqr_matches_householder_kernel(ctx, monkeypatch):
