@@ -326,20 +326,31 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     // as blocks of nb columns = contiguous slabs of n nb doubles
     {
       void* pst = nullptr;
-      BK_TRY(ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(comm->nranks + 1) * nb * n * (int64_t)sizeof(double), &pst));
-      double* send = (double*)pst;
-      double* recv = send + nb * n;
-      BK_HIP(hipMemsetAsync(send, 0, (size_t)(nb * n) * sizeof(double), st));
-      if (nloc > 0) BK_HIP(hipMemcpyAsync(send, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      double *send = nullptr, *recv = nullptr;
+      auto stage = [&]() -> int {     // (local steps before a collective: their status is agreed, see `agreed`)
+        BK_TRY(ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(comm->nranks + 1) * nb * n * (int64_t)sizeof(double), &pst));
+        send = (double*)pst;
+        recv = send + nb * n;
+        BK_HIP(hipMemsetAsync(send, 0, (size_t)(nb * n) * sizeof(double), st));
+        if (nloc > 0) BK_HIP(hipMemcpyAsync(send, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return BIGKRLS_OK;
+      };
+      BK_TRY(agreed(stage()));
       BK_TRY(comm_all_gather(comm, send, recv, nb * n));
-      BK_HIP(hipMemcpyAsync(Kfull, recv, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      BK_TRY(agreed(hipMemcpyAsync(Kfull, recv, (size_t)(n * n) * sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess
+                        ? BIGKRLS_OK : BIGKRLS_EHIP));
     }
     BK_TRY(comm_agree(comm, eigen(ctx, Kfull, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper, comm->rank, comm->nranks)));
     if (lastkeeper > 0) BK_TRY(comm_all_reduce(comm, dQ, n * lastkeeper, COMM_SUM));
   }
-  BK_TRY(pinned_get(ctx, pin_doubles, &pin));   // (the eigensolver may have grown -- and so moved -- the pinned buffer)
   std::vector<double> vals(neig);
-  BK_TRY(download(ctx, vals.data(), dvals, neig, pin));
+  {
+    auto fetch_vals = [&]() -> int {
+      BK_TRY(pinned_get(ctx, pin_doubles, &pin));   // (the eigensolver may have grown -- and so moved -- the pinned buffer)
+      return download(ctx, vals.data(), dvals, neig, pin);
+    };
+    BK_TRY(agreed(fetch_vals()));
+  }
   for (int64_t i = 0; i < neig; ++i)
     if (std::isnan(vals[i]))
       return fail("Missing eigenvalues prevent bigKRLS from obtaining the regularization parameter lambda.\n\t"
@@ -391,10 +402,17 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     BK_TRY(comm_gather_rows(comm, dSloc, nloc, std::max<int64_t>(nloc, 1), 1, nb, n, dyhat, n));
   }
   std::vector<double> coeffs(n), yhat(n);
-  BK_HIP(hipMemcpyAsync(pin, dc, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));        // dyhat follows dc
-  BK_HIP(hipStreamSynchronize(st));
-  std::memcpy(coeffs.data(), pin, (size_t)n * sizeof(double));
-  std::memcpy(yhat.data(), pin + n, (size_t)n * sizeof(double));
+  {
+    auto fetch_c = [&]() -> int {
+      BK_HIP(hipMemcpyAsync(pin, dc, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));    // dyhat follows dc
+      BK_HIP(hipStreamSynchronize(st));
+      // (out of the pinned buffer before the status is agreed: the agreement stages its words through the same buffer)
+      std::memcpy(coeffs.data(), pin, (size_t)n * sizeof(double));
+      std::memcpy(yhat.data(), pin + n, (size_t)n * sizeof(double));
+      return BIGKRLS_OK;
+    };
+    BK_TRY(agreed(fetch_c()));              // (the derivative pass below has collectives of its own)
+  }
   timer.mark();                                                           // coeffs
 
   double sigmasq = NaN;
@@ -409,6 +427,9 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     for (int64_t i = 0; i < k; ++i) wv[i] = sigmasq * std::pow(vals[i] + lambda, -2.0);                // :299
     const double sd2 = y_sd * y_sd;
     if (out->d_vcov_c || out->d_vcov_fitted) {
+     // (one local stretch between the collectives of the coefficients and those of the derivative pass: its status is
+     //  agreed at the end, so that a rank that fails here does not leave its peers waiting in the next all-gather)
+     auto variance_matrices = [&]() -> int {
       void* pm = nullptr;
       BK_TRY(ws_get(ctx, SLOT_FIT_M, n * k * (int64_t)sizeof(double), &pm));
       double* dM = (double*)pm;
@@ -443,6 +464,9 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
         BK_HIP(hipStreamSynchronize(st));
       }
       timer.mark();                                                       // vcov_fitted
+      return BIGKRLS_OK;
+     };
+     BK_TRY(agreed(variance_matrices()));
     } else {
       timer.mark();
       timer.mark();
