@@ -470,9 +470,17 @@ def _run_folds(jobs, contexts, fit_fn, predict_fn):
     return results
 
 
-def _fold_contexts(ctx, devices):
+def _fold_contexts(ctx, devices, folds_per_device=1):
     """One context per requested GPU. `devices`: None (the given / default context only), "all",
-    or a list of device indices (or of ready-made contexts)."""
+    or a list of device indices (or of ready-made contexts). `folds_per_device` = 2 adds a second context
+    with a stream of its own on every device (two folds side by side per GPU)."""
+    if folds_per_device not in (1, 2):
+        # three or more decompositions side by side can hold each other's persistent kernels off the GPU: every
+        # watchdog then fires and the fits are redone with the launch-per-step kernels (correct, but slower than one)
+        raise ValueError("folds_per_device must be 1 or 2")
+    if folds_per_device == 2:
+        base = _fold_contexts(ctx, devices)
+        return base + [Context(c.device_index, own_stream=True) for c in base]
     if devices is None:
         return [ctx or default_context()]
     import torch
@@ -493,7 +501,7 @@ def _fold_contexts(ctx, devices):
 
 
 def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, folds=None,
-                  ctx: Optional[Context] = None, devices=None, **fit_args) -> BigKRLSCV:
+                  ctx: Optional[Context] = None, devices=None, folds_per_device=1, **fit_args) -> BigKRLSCV:
     """crossvalidate.bigKRLS (R/bigKRLS.R:1146-1336).
 
     R partitions with set.seed(seed); sample() (:1168,1179,1232), a stream that
@@ -505,6 +513,10 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
     independent fits (the loop at :1268-1282), so they run as replicas, one fold per GPU at a time
     (last row): one context and one worker thread per GPU, no data-path
     collective. The statistics are identical to the sequential loop's.
+    `folds_per_device` = 2 runs two folds side by side on every GPU (a second context with its own stream and
+    worker thread): fold-sized fits are bound by latency chains that leave most of the GPU idle -- eight fits of
+    N = 4000 take 0.33 s one after the other and 0.20 s two at a time (`tools/cv_concurrency.py`); results bitwise
+    those of the sequential loop (tests/test_gpu_fit.py, two contexts). More than two is refused: see _fold_contexts.
     """
     if (Kfolds is None) + (ptesting is None) != 1:
         raise ValueError("Specify either Kfolds or ptesting but not both.")
@@ -533,7 +545,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
             r["MSE_AME_oos"] = float(np.mean((ytest - yhat_ame) ** 2))            # :1213
         return r
 
-    contexts = _fold_contexts(ctx, devices)
+    contexts = _fold_contexts(ctx, devices, folds_per_device)
     if ptesting is not None:
         if ptesting < 0 or ptesting > 100:
             raise ValueError("ptesting, the percentage of data to be used for validation, must be between 0 and 100.")

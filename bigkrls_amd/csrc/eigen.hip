@@ -2479,8 +2479,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     if (mode == EIG_FULL) BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
     if (mode == EIG_FULL && getenv("BIGKRLS_VERBOSE") && s1.pqc) {
       double nfb = 0.0;
-      BK_HIP(hipMemcpyAsync(&nfb, s1.pqc + PQC_OFF_SLICES + PQC_NG + 32, sizeof(double), hipMemcpyDeviceToHost, st));
-      BK_HIP(hipStreamSynchronize(st));
+      PinnedFetch pfb(ctx, 1);       // (never a device -> pageable copy: the runtime would pin / unpin the page)
+      BK_TRY(pfb.add(&nfb, s1.pqc + PQC_OFF_SLICES + PQC_NG + 32, sizeof(double)));
+      BK_TRY(pfb.finish());
       fprintf(stderr, "[bigkrls]   panels left to the Householder kernel by pq_chol: %d\n", (int)nfb);
     }
     {

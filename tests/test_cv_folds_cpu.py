@@ -74,3 +74,15 @@ def test_fold_errors_surface_in_the_caller(monkeypatch):
     X, y = orc.synth(60, 2, 6)
     with pytest.raises(RuntimeError, match="device 1 failed"):
         bk.crossvalidate(y, X, Kfolds=4, devices=[FakeContext(0), FakeContext(1)], seed=3)
+
+
+def test_folds_per_device_is_one_or_two():
+    """crossvalidate(folds_per_device=...): a second context per device, never more (three decompositions side by
+    side can keep each other's persistent kernels off the GPU)."""
+    import pytest
+    from bigkrls_amd import api
+    a = FakeContext(0)
+    assert api._fold_contexts(a, [a]) == [a]
+    for bad in (0, 3, 8):
+        with pytest.raises(ValueError):
+            api._fold_contexts(a, [a], folds_per_device=bad)

@@ -355,6 +355,13 @@ def test_crossvalidate_fold_parallel_contexts(ctx):
         assert two[k] == seq[k], k                      # deterministic kernels: bitwise the same on any context
     c0 = two["fold_1"]["trained"]["_ctx"]
     assert two["fold_3"]["trained"]["_ctx"] is c0 and two["fold_2"]["trained"]["_ctx"] is not c0
+    # (iii) the same thing asked for by number: two folds at a time on the one device
+    pair = bk.crossvalidate(y, X, Kfolds=4, folds=folds, ctx=ctx, folds_per_device=2)
+    assert pair["devices"] == [0, 0]
+    for k in ["R2_is", "R2_oos", "MSE_is", "MSE_oos", "R2AME_is", "R2AME_oos"]:
+        assert pair[k] == seq[k], k
+    with pytest.raises(ValueError):
+        bk.crossvalidate(y, X, Kfolds=4, folds=folds, ctx=ctx, folds_per_device=3)
 
 
 @pytest.mark.gpu
