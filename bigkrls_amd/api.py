@@ -475,8 +475,9 @@ def _fold_contexts(ctx, devices, folds_per_device=1):
     or a list of device indices (or of ready-made contexts). `folds_per_device` = 2 adds a second context
     with a stream of its own on every device (two folds side by side per GPU)."""
     if folds_per_device not in (1, 2):
-        # three or more decompositions side by side can hold each other's persistent kernels off the GPU: every
-        # watchdog then fires and the fits are redone with the launch-per-step kernels (correct, but slower than one)
+        # measured (tools/cv_concurrency.py, N = 4000): two at a time 25 ms per fit against 41 one after the other;
+        # three 37 (an odd split of the GPU between the persistent kernels), four 22-28: the second context is where
+        # the gain is, and every further one costs its own N x N workspaces
         raise ValueError("folds_per_device must be 1 or 2")
     if folds_per_device == 2:
         base = _fold_contexts(ctx, devices)
@@ -516,7 +517,7 @@ def crossvalidate(y, X, seed=None, Kfolds=None, ptesting=None, train_idx=None, f
     `folds_per_device` = 2 runs two folds side by side on every GPU (a second context with its own stream and
     worker thread): fold-sized fits are bound by latency chains that leave most of the GPU idle -- eight fits of
     N = 4000 take 0.33 s one after the other and 0.20 s two at a time (`tools/cv_concurrency.py`); results bitwise
-    those of the sequential loop (tests/test_gpu_fit.py, two contexts). More than two is refused: see _fold_contexts.
+    those of the sequential loop (tests/test_gpu_fit.py, two contexts). More than two gain little (see _fold_contexts) and are refused.
     """
     if (Kfolds is None) + (ptesting is None) != 1:
         raise ValueError("Specify either Kfolds or ptesting but not both.")
