@@ -1,6 +1,6 @@
 """Eigen-decomposition residuals over a sweep of sizes that cross every size-dependent switch of the
 dense path (QL leaves n > 64, two-stage n > 256, panel groups of 4, factored D&C levels n >= 4096,
-two-level panel-QR exchange n > ~7000) -- development probe."""
+two-level panel-QR exchange n > ~7000) -- development probe.  python tools/size_sweep.py [large]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -11,6 +11,10 @@ ctx = bk.Context(0)
 rng = np.random.default_rng(3)
 sizes = [2, 3, 17, 63, 64, 65, 66, 127, 129, 255, 256, 257, 258, 300, 321, 449, 512, 513, 577, 640, 705, 1000,
          1023, 1025, 2047, 2049, 3000, 4095, 4096, 4097, 5003, 6912, 6913, 7169, 9001]
+# round 4: the stage-2 back-transform as chains (n > 8000), four panels per trailing update (trailing matrix >= 12 800
+# rows, i.e. n >= 13 121), pairs below (>= 10 752)
+if len(sys.argv) > 1 and sys.argv[1] == "large":
+    sizes = [7999, 8000, 8001, 8033, 8191, 10751, 11009, 11073, 13055, 13121, 13185, 13377, 13441, 14001]
 bad = 0
 for n in sizes:
     p = 4
