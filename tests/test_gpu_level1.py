@@ -359,6 +359,25 @@ def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, ne
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nbytes", [1, 8, 65535, 65536 * 2 + 8, (16 << 20) * 2, (16 << 20) * 5 + 24])
+def test_c_abi_host_copies_are_staged_in_pieces(lib, ctx, nbytes):
+    """bigkrls_h2d / bigkrls_d2h copy caller memory through two pinned halves (64 KB ... 16 MB each, csrc/capi.hip
+    staged_copy): sizes below one half, of exactly two halves, and of several pieces with a ragged tail, byte for byte."""
+    import ctypes as C
+    rng = np.random.default_rng(nbytes % 1000)
+    src = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+    back = np.zeros(nbytes, dtype=np.uint8)
+    dptr = C.c_void_p()
+    check(lib, lib.bigkrls_dev_alloc(ctx.handle, nbytes, C.byref(dptr)))
+    try:
+        check(lib, lib.bigkrls_h2d(ctx.handle, dptr, src.ctypes.data_as(C.c_void_p), nbytes))
+        check(lib, lib.bigkrls_d2h(ctx.handle, back.ctypes.data_as(C.c_void_p), dptr, nbytes))
+    finally:
+        check(lib, lib.bigkrls_dev_free(ctx.handle, dptr))
+    assert np.array_equal(back, src)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,order", [((1000, 7), "C"), ((1000, 7), "F"), ((1, 1), "C"), ((5, 0), "C"),
                                          ((3000, 3001), "C")])
 def test_host_device_transfers_round_trip(ctx, monkeypatch, shape, order):
