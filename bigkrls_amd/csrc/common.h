@@ -299,5 +299,10 @@ int dist_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y);
 int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
                         int64_t row0);
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
+// several panels per trailing update (the group that starts at k0): see csrc/eigen.hip
+int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0);
+int dist_s1_thin_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, int64_t k0);
+int dist_s1_update_cols_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                              int64_t row0, int64_t k0, int nblk);
 
 }  // namespace bk

@@ -239,6 +239,34 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
     BK_TRY(bcast_strip(0, b));
     if (status == BIGKRLS_OK) local(dist_s1_panel(ctx, n, 0, sbuf));
   }
+  // ---- four / two panels per trailing update while the trailing matrix is large (the single-GPU loop's aggregation
+  //      without its pieces): the update of a group is applied after its last panel; the later panels' products run on
+  //      the stale column blocks and are corrected with the group's pending blocks (replicated thin products)
+  for (int G = dist_s1_group_size(ctx, n, k); G > 0; G = dist_s1_group_size(ctx, n, k)) {
+    const int64_t k0 = k;
+    for (int j = 0; j < G; ++j, k += b) {
+      const int64_t m = n - k - b;
+      const int64_t la0 = std::min<int64_t>(std::max<int64_t>(k + b - c0, 0), ncl);
+      const int64_t nact = ncl - la0;
+      double* Aact = A + la0 * n + (k + b);
+      const int64_t row0 = nact > 0 ? (c0 + la0) - (k + b) : 0;
+      if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, row0, Y, m));
+      BK_TRY(comm_all_reduce(comm, Y, m * b, COMM_SUM));
+      if (status == BIGKRLS_OK) local(dist_s1_thin_group(ctx, n, k, Y, k0));
+      const int64_t nxt = k + b;
+      int64_t first = 0;
+      if (has_panel(nxt)) {
+        if (nxt / nb == rank) {                          // the next panel's columns: every pending block, before the strip leaves
+          first = std::min<int64_t>(b, nact);
+          if (status == BIGKRLS_OK) local(dist_s1_update_cols_group(ctx, n, k, Aact, n, first, row0, k0, j + 1));
+        }
+        BK_TRY(bcast_strip(nxt, b));
+        if (status == BIGKRLS_OK) local(dist_s1_panel_begin(ctx, n, nxt, sbuf));
+      }
+      if (j == G - 1 && status == BIGKRLS_OK)            // the group's update of the own columns, beside the next factorisation
+        local(dist_s1_update_cols_group(ctx, n, k, Aact + first * n, n, nact - first, row0 + first, k0, G));
+    }
+  }
   while (has_panel(k)) {
     const int64_t m = n - k - b;
     const int64_t la0 = std::min<int64_t>(std::max<int64_t>(k + b - c0, 0), ncl);   // first own column inside the trailing matrix

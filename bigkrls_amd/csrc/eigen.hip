@@ -2454,7 +2454,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
                           hipMemcpyHostToDevice, st));
     if (mode != EIG_RESUME) BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
-    if (mode == EIG_FULL && n >= S1_AGG_MIN_M + 4 * S2_B) {
+    if ((mode == EIG_FULL || mode == EIG_SETUP_ONLY) && n >= S1_AGG_MIN_M + 4 * S2_B) {
       // reflector blocks of the two panel groups whose trailing update is pending (stage1_to_band)
       void* pagg = nullptr;
       const int64_t blk = N * 4 * S2_B;
@@ -2790,6 +2790,72 @@ int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, i
     return BIGKRLS_OK;
   }
   return gemm(ctx, 0, 1, m, ncols, 2 * S2_B, -1.0, PZ1, m, PZ2 + row0, m, 1.0, Acols, lda);
+}
+
+// ---- several panels per trailing update in the partitioned stage 1 (no pieces: the update of a group of G = 4 or 2
+//      panels is applied after its last panel; panel j's product with the stale column blocks is corrected with the j
+//      pending blocks of the group, as in stage1_to_band) -------------------------------------------------------------
+// size of the group that may start at panel k0: 4 (trailing matrix >= 12 800 rows), 2 (>= 10 752), or 0
+int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0) {
+  DistS1* ds = nullptr;
+  if (dist_state(ctx, n, &ds) != BIGKRLS_OK || ds->ops.ws.aggPZ1[0] == nullptr || !ds->ops.fused_small) return 0;
+  static const int env = [] { const char* e = getenv("BIGKRLS_S1AGG"); return e ? atoi(e) : -1; }();
+  if (env == 0) return 0;
+  const int b = S2_B;
+  auto panels = [&](int g) {
+    for (int j = 0; j < g; ++j)
+      if (!ds->ops.has_panel((int)(k0 + j * b))) return false;
+    return true;
+  };
+  if (env != 2 && panels(4) && n - k0 - 4 * b >= S1_QUAD_MIN_M) return 4;
+  if (panels(2) && n - k0 - 2 * b >= S1_AGG_MIN_M) return 2;
+  return 0;
+}
+
+// the thin products of panel k = k0 + 64 j of the group that starts at k0, from the summed Y = (stale A22) V, written
+// into block j of the group's [V Z ...] / [Z V ...] buffers (n x 512 each: the layout of stage1_to_band's groups of four)
+int dist_s1_thin_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, int64_t k0) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_TRY(dist_s1_wait_panel(ctx, ds));
+  const int b = S2_B;
+  const int64_t m = n - k - b, off = k - k0;
+  const int j = (int)(off / b);
+  BK_REQUIRE(Y && m > 0 && off >= 0 && off % b == 0 && j < 4 && ds->ops.ws.aggPZ1[0], "s1_thin_group: bad arguments");
+  double *PZ1 = ds->ops.ws.aggPZ1[0], *PZ2 = ds->ops.ws.aggPZ1[1];
+  const int64_t ldg = ds->ops.ws.aggLd;
+  if (j > 0) {        // Y -= U (U'^T V) over the j pending blocks: their update has not reached the column blocks yet
+    double* C = ds->ops.ws.aggC;
+    BK_TRY(gemm(ctx, 1, 0, 2 * b * j, b, m, 1.0, PZ2 + off, ldg, ds->ops.ws.Vp, m, 0.0, C, 2 * b * j));
+    BK_TRY(gemm(ctx, 0, 0, m, b, 2 * b * j, -1.0, PZ1 + off, ldg, C, 2 * b * j, 1.0, Y, m));
+  }
+  const int64_t roff = off + (int64_t)j * 2 * b * ldg;
+  return ds->ops.small_products_to((int)k, Y, nullptr, PZ1 + roff, PZ2 + roff, ldg);
+}
+
+// A22[:, cols] -= U U'[cols, :]' over the first `nblk` blocks of the group that starts at k0 (fewer than the whole group:
+// for the next panel's columns only); the trailing matrix is panel k's
+int dist_s1_update_cols_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
+                              int64_t row0, int64_t k0, int nblk) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  const int b = S2_B;
+  const int64_t m = n - k - b, off = k - k0;
+  BK_REQUIRE(m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m && off >= 0 && off % b == 0 && nblk >= 1 && nblk <= 4 &&
+                 off / b < nblk && ds->ops.ws.aggPZ1[0], "s1_update_cols_group: bad arguments");
+  if (ncols == 0) return BIGKRLS_OK;
+  BK_REQUIRE(Acols && lda >= m, "s1_update_cols_group: bad column block");
+  const int64_t ldg = ds->ops.ws.aggLd, kk = 2 * b * nblk;
+  const double *PZ1 = ds->ops.ws.aggPZ1[0] + off, *PZ2 = ds->ops.ws.aggPZ1[1] + off;
+  if (ncols >= 128) {
+    if (row0 > 0) BK_TRY(gemm(ctx, 0, 1, row0, ncols, kk, -1.0, PZ1, ldg, PZ2 + row0, ldg, 1.0, Acols, lda));
+    BK_TRY(syrk_mirror(ctx, ncols, kk, -1.0, PZ1 + row0, ldg, PZ2 + row0, ldg, Acols + row0, lda, 0, -1, true));
+    const int64_t below = m - row0 - ncols;
+    if (below > 0)
+      BK_TRY(gemm(ctx, 0, 1, below, ncols, kk, -1.0, PZ1 + row0 + ncols, ldg, PZ2 + row0, ldg, 1.0, Acols + row0 + ncols, lda));
+    return BIGKRLS_OK;
+  }
+  return gemm(ctx, 0, 1, m, ncols, kk, -1.0, PZ1, ldg, PZ2 + row0, ldg, 1.0, Acols, lda);
 }
 
 int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Acols, int64_t lda, int64_t ncols,

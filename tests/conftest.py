@@ -32,6 +32,11 @@ WORLD_CASES = {
     "rccl_mock_dense_world3_ragged": ["2500", "6", "3", "--rccl-mock"],
     "rccl_mock_krylov_world2": ["17000", "10", "2", "--krylov", "60", "--rccl-mock", "--default-knobs"],
     "rccl_mock_dense_world4_empty_rank": ["300", "4", "4", "--eigtrunc", "0.001", "--rccl-mock"],
+    # n large enough for the partitioned stage 1 to aggregate panels per trailing update: pairs (trailing matrix >= 10 752
+    # rows: the first seven pairs at n = 11 700), three ranks with a ragged last block; groups of four (>= 12 800 rows: two
+    # groups at n = 13 500) followed by pairs, two ranks over the RCCL path
+    "dense_world3_pairs": ["11700", "6", "3", "--eigtrunc", "0.001"],
+    "rccl_mock_dense_world2_groups": ["13500", "6", "2", "--eigtrunc", "0.001", "--rccl-mock", "--default-knobs"],
 }
 # `python bench.py --gpus 2` end to end on the one GPU: its own launcher, two rank processes, the library's RCCL
 # communicator over tests/mock_rccl (BIGKRLS_BENCH_SHARE_GPU=1: both ranks on device 0, gloo for the program's barrier)
