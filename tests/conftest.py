@@ -44,6 +44,7 @@ BENCH_CASES = {
     "bench_gpus2_c2": ["--gpus", "2", "--config", "C2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
 }
 _world_runs = {}
+_supervisor = None
 
 
 def pytest_sessionstart(session):
@@ -59,6 +60,7 @@ def pytest_sessionstart(session):
             return
     except Exception:
         return
+    import json
     import subprocess
     import tempfile
     # the stand-in for librccl is built by __graft_entry__.build(); build it here if it did not travel (no GPU needed)
@@ -66,38 +68,50 @@ def pytest_sessionstart(session):
     if not os.path.exists(mock):
         subprocess.run(["make", "-C", os.path.dirname(mock)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     have_mock = os.path.exists(mock)
+    jobs = []
+    tmpdir = tempfile.mkdtemp(prefix="bigkrls_world_")
     for name, args in WORLD_CASES.items():
         if "--rccl-mock" in args and not have_mock:
             continue                                   # (the test of this case skips)
-        log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
-        # Some thirty rank processes share the one GPU with this session: the persistent kernels of the eigensolver spin
-        # on messages between workgroups that must be co-resident, which nothing guarantees here -- most cases use the
-        # launch-per-step kernels (a fired watchdog is replayed, but each replay costs seconds); "--default-knobs"
-        # cases run the library as shipped.
-        env = dict(os.environ, BIGKRLS_PQ="steps", BIGKRLS_BC="wavefront")
+        # The rank processes share the one GPU with each other and with this session: the persistent kernels of the
+        # eigensolver spin on messages between workgroups that must be co-resident, which nothing guarantees here --
+        # most cases use the launch-per-step kernels (a fired watchdog is replayed, but each replay costs seconds);
+        # "--default-knobs" cases run the library as shipped.
+        env = {"BIGKRLS_PQ": "steps", "BIGKRLS_BC": "wavefront"}
         if "--default-knobs" in args:
-            env = dict(os.environ)
-        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_world_gpu.py")] + args,
-                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env)
-        _world_runs[name] = (proc, log.name)
-
-
+            env = {"BIGKRLS_PQ": None, "BIGKRLS_BC": None}
+        log = os.path.join(tmpdir, f"{name}.log")
+        jobs.append([name, [sys.executable, os.path.join(ROOT, "tests", "_dist_world_gpu.py")] + args, env, log])
+        _world_runs[name] = log
     for name, args in BENCH_CASES.items():
         if not have_mock:
             continue
-        log = tempfile.NamedTemporaryFile("w+", prefix=f"bigkrls_{name}_", suffix=".log", delete=False)
-        env = dict(os.environ, BIGKRLS_BENCH_SHARE_GPU="1",
-                   BIGKRLS_RCCL_LIB=os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so"))
-        env.pop("WORLD_SIZE", None)
-        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args,
-                                stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env)
-        _world_runs[name] = (proc, log.name)
+        log = os.path.join(tmpdir, f"{name}.log")
+        env = {"BIGKRLS_BENCH_SHARE_GPU": "1", "BIGKRLS_RCCL_LIB": mock, "WORLD_SIZE": None}
+        jobs.append([name, [sys.executable, os.path.join(ROOT, "bench.py")] + args, env, log])
+        _world_runs[name] = log
+    # one supervisor runs them a few at a time (tests/_world_supervisor.py); it is started here, before this process
+    # touches the GPU, and never touches it itself
+    global _supervisor
+    _supervisor = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_world_supervisor.py"), json.dumps(jobs)],
+                                   cwd=ROOT)
+
+
+def wait_world_run(log, timeout=1500.0):
+    """(exit code, log text) of a supervised job; waits for its .rc file."""
+    import time
+    t_end = time.time() + timeout
+    while not os.path.exists(log + ".rc"):
+        if time.time() > t_end or (_supervisor is not None and _supervisor.poll() is not None and not os.path.exists(log + ".rc")):
+            text = open(log).read() if os.path.exists(log) else ""
+            return -999, text + "\n[conftest] the job did not finish (supervisor gone or timeout)"
+        time.sleep(0.2)
+    return int(open(log + ".rc").read().strip()), open(log).read()
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for proc, _ in _world_runs.values():
-        if proc.poll() is None:
-            proc.kill()
+    if _supervisor is not None and _supervisor.poll() is None:
+        _supervisor.kill()                       # (its own PID; running rank processes end with their collectives' peers)
 
 
 @pytest.fixture(scope="session")

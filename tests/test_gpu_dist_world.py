@@ -2,7 +2,7 @@
 (tests/_dist_world_gpu.py): the partitioned dense stage 1 with column-block offsets (a ragged last block, a rank
 that owns nothing), the split back-transform, the sharded block Lanczos, the replicated decomposition of a tiny
 problem, the row-block lambda search; every rank compared with the single-process fit of the same data. The rank
-processes are started by conftest.py at session start. RCCL itself refuses two ranks on one device: it is covered
+processes are started at session start (conftest.py: one supervisor process that runs the cases four at a time). RCCL itself refuses two ranks on one device: it is covered
 at world size 1 (test_gpu_fit.py), and the library's RCCL code path -- unique id, bigkrls_comm_create, the dlopen'd
 function table, collectives asynchronous on the context's stream, default kernels -- at world sizes 2-4 over
 tests/mock_rccl (the "rccl_mock_*" cases and `bench.py --gpus 2`)."""
@@ -10,7 +10,7 @@ import pytest
 
 import json
 
-from conftest import BENCH_CASES, WORLD_CASES
+from conftest import BENCH_CASES, WORLD_CASES, wait_world_run
 
 pytestmark = pytest.mark.gpu
 
@@ -19,13 +19,7 @@ pytestmark = pytest.mark.gpu
 def test_world_n_hip_backend_matches_single_fit(world_runs, name):
     if name not in world_runs:
         pytest.skip("rank processes were not started (no GPU at session start)")
-    proc, log = world_runs[name]
-    try:
-        rc = proc.wait(timeout=900)
-    finally:
-        if proc.poll() is None:
-            proc.kill()
-    text = open(log).read()
+    rc, text = wait_world_run(world_runs[name])
     world = int(WORLD_CASES[name][2])
     assert rc == 0, text[-4000:]
     ok_lines = [ln for ln in text.splitlines() if ln.startswith("rank ") and ln.rstrip().endswith(" OK")]
@@ -43,13 +37,7 @@ def test_bench_gpus2_through_the_rccl_path(world_runs, name):
     of stdout is rank 0's JSON line with n_gpus = 2 and the rank count read back from the library."""
     if name not in world_runs:
         pytest.skip("rank processes were not started (no GPU at session start)")
-    proc, log = world_runs[name]
-    try:
-        rc = proc.wait(timeout=900)
-    finally:
-        if proc.poll() is None:
-            proc.kill()
-    text = open(log).read()
+    rc, text = wait_world_run(world_runs[name])
     assert rc == 0, text[-4000:]
     line = [ln for ln in text.splitlines() if ln.lstrip().startswith("{")][-1]
     res = json.loads(line)
