@@ -180,50 +180,6 @@ static int default_ctx(bigkrls_ctx** out) {
   return BIGKRLS_OK;
 }
 
-// Host <-> device copies of caller memory go through the two halves of the context's pinned buffer: the caller's pages
-// (an R big.matrix, a numpy array) are pageable, and a copy straight to or from them makes the runtime pin and unpin
-// them -- with another context's persistent kernels on the GPU that has stalled a process for minutes.
-int staged_copy(bigkrls_ctx* ctx, char* dst, const char* src, int64_t nbytes, bool to_host) {
-  hipStream_t st = ctx->stream;
-  // (a buffer of its own: the fit keeps pointers into h_pinned across collectives, and a callback table's collectives
-  //  come back into these entry points)
-  const int64_t half_d = std::min<int64_t>(std::max<int64_t>((nbytes / 8 + 1) / 2 + 1, 1 << 13), (int64_t)1 << 21);   // 64 KB .. 16 MB per half
-  if (ctx->h_stage_doubles < 2 * half_d) {
-    if (ctx->h_stage) BK_HIP(hipHostFree(ctx->h_stage));
-    ctx->h_stage = nullptr;
-    ctx->h_stage_doubles = 0;
-    BK_HIP(hipHostMalloc((void**)&ctx->h_stage, (size_t)(2 * half_d) * sizeof(double), hipHostMallocDefault));
-    ctx->h_stage_doubles = 2 * half_d;
-  }
-  double* pin = ctx->h_stage;
-  const int64_t half = half_d * (int64_t)sizeof(double);
-  char* slot[2] = {(char*)pin, (char*)pin + half};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  for (auto& e : ev) BK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  struct Guard { hipEvent_t* e; ~Guard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } guard{ev};
-  const int64_t np = (nbytes + half - 1) / half;
-  auto len = [&](int64_t i) { return std::min<int64_t>(half, nbytes - i * half); };
-  for (int64_t i = 0; i < np; ++i) {
-    const int s = (int)(i & 1);
-    if (i >= 2) {
-      BK_HIP(hipEventSynchronize(ev[s]));                      // piece i - 2 has left (or filled) this half
-      if (to_host) std::memcpy(dst + (i - 2) * half, slot[s], (size_t)len(i - 2));
-    }
-    if (to_host) {
-      BK_HIP(hipMemcpyAsync(slot[s], src + i * half, (size_t)len(i), hipMemcpyDeviceToHost, st));
-    } else {
-      std::memcpy(slot[s], src + i * half, (size_t)len(i));
-      BK_HIP(hipMemcpyAsync(dst + i * half, slot[s], (size_t)len(i), hipMemcpyHostToDevice, st));
-    }
-    BK_HIP(hipEventRecord(ev[s], st));
-  }
-  BK_HIP(hipStreamSynchronize(st));
-  if (to_host)
-    for (int64_t i = std::max<int64_t>(0, np - 2); i < np; ++i)
-      std::memcpy(dst + i * half, slot[i & 1], (size_t)len(i));
-  return BIGKRLS_OK;
-}
-
 // RAII device staging buffer for Level 1
 struct DevBuf {
   double* p = nullptr;
@@ -242,11 +198,11 @@ struct DevBuf {
   }
   int upload(bigkrls_ctx* ctx, const double* h, int64_t n) {
     BK_TRY(alloc(n));
-    if (n > 0) BK_TRY(staged_copy(ctx, (char*)p, (const char*)h, n * (int64_t)sizeof(double), false));
+    if (n > 0) BK_HIP(hipMemcpyAsync(p, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     return BIGKRLS_OK;
   }
   int download(bigkrls_ctx* ctx, double* h, int64_t n) {
-    if (n > 0) return staged_copy(ctx, (char*)h, (const char*)p, n * (int64_t)sizeof(double), true);
+    if (n > 0) BK_HIP(hipMemcpyAsync(h, p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     BK_HIP(hipStreamSynchronize(ctx->stream));
     return BIGKRLS_OK;
   }
@@ -328,7 +284,6 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   (void)bigkrls_ctx_release_workspace(ctx);
   if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -399,14 +354,18 @@ int bigkrls_h2d(bigkrls_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
   BK_TRY(check_ctx(ctx));
   if (nbytes <= 0) return BIGKRLS_OK;
   BK_REQUIRE(dst && src, "h2d: null pointer");
-  return staged_copy(ctx, (char*)dst, (const char*)src, nbytes, false);
+  BK_HIP(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  return BIGKRLS_OK;
 }
 
 int bigkrls_d2h(bigkrls_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
   BK_TRY(check_ctx(ctx));
   if (nbytes <= 0) return BIGKRLS_OK;
   BK_REQUIRE(dst && src, "d2h: null pointer");
-  return staged_copy(ctx, (char*)dst, (const char*)src, nbytes, true);
+  BK_HIP(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  return BIGKRLS_OK;
 }
 
 int bigkrls_d2d(bigkrls_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
@@ -756,7 +715,7 @@ int bigkrls_derivmat(const double* X, int64_t n, int64_t p, const double* K, con
   BK_TRY(deriv_rows(ctx, dK.p, n, n, n, 0, dX.p, p, n, isbin.data(), dc.p, sigma, dD.p, n, dS.p, n));
   BK_TRY(dD.download(ctx, D, n * p));
   // reuse K's device buffer for V
-  BK_TRY(staged_copy(ctx, (char*)dK.p, (const char*)V, n * n * (int64_t)sizeof(double), false));
+  BK_HIP(hipMemcpyAsync(dK.p, V, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   BK_TRY(dVS.alloc(n * p));
   BK_TRY(dout.alloc(p));
   BK_TRY(gemm(ctx, 0, 0, n, p, n, 1.0, dK.p, n, dS.p, n, 0.0, dVS.p, n));

@@ -67,8 +67,6 @@ struct bigkrls_ctx {
   // pinned host scratch for small scalar read-backs
   double* h_pinned = nullptr;
   int64_t h_pinned_doubles = 0;
-  double* h_stage = nullptr;        // pinned staging of bigkrls_h2d / bigkrls_d2h (two halves), separate from h_pinned:
-  int64_t h_stage_doubles = 0;      // those entry points are also called from inside collectives (callback tables)
   // optional HIP-event sampling of named kernels (bench.py roofline numbers)
   bool profile = false;
   struct ProfSample { hipEvent_t e0, e1; double work; };

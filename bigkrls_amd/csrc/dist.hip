@@ -304,6 +304,18 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
   void* pq = nullptr;
   status = eigen(ctx, nullptr, n, n, neig, dvals, neig, eigtrunc, dQ, n, &nv, rank, world, EIG_RESUME);
   BK_TRY(comm_agree(comm, status));
+  {
+    // The decomposition is replicated with deterministic kernels, so every rank keeps the same number of pairs; the
+    // exchange below is sized by it. Checked rather than assumed: a rank that disagrees (memory corruption, a GPU
+    // fault) must come back as an error on every rank, not as a collective with mismatched sizes.
+    double mm[2] = {(double)nv, -(double)nv};
+    BK_TRY(comm_all_reduce_host(comm, mm, 2, COMM_MIN));
+    if (mm[0] != -mm[1]) {
+      set_error("eigen (distributed): the ranks disagree on the number of kept eigenpairs (" + std::to_string((long long)mm[0]) +
+                " ... " + std::to_string((long long)-mm[1]) + "); the replicated decomposition was not reproduced bit for bit");
+      return BIGKRLS_EHIP;
+    }
+  }
   if (h_lastkeeper) *h_lastkeeper = nv;
   if (world == 1 || nv == 0) return BIGKRLS_OK;
   // all-gather of the back-transformed column blocks (rank r holds columns nv r / world .. nv (r + 1) / world)

@@ -2212,6 +2212,16 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
       double ag[2] = {-rmax, std::fabs(theta[0])};
       BK_TRY(kry_agree_min(kop, ag, 2));
       if (!(-ag[0] <= 10.0 * tol * ag[1])) refine = true;    // also NaN
+      // ... and a residual that is not even small against theta_1 means that the recurrence K B_j = ... did not hold
+      // (a product or an exchange delivered wrong data): the Ritz pairs of T are then no pairs of K at all. Every rank
+      // sees the same agreed figures, so every rank returns the error.
+      if (!(-ag[0] <= 1e-3 * ag[1])) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "eigen (Krylov): the Ritz pairs fail the check against K itself (residual %.3e, theta_1 %.3e): "
+                                  "the block recurrence was corrupted", -ag[0], ag[1]);
+        set_error(buf);
+        return BIGKRLS_ENOCONV;
+      }
     }
     dvals_final = dtheta;
   }

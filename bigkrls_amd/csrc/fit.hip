@@ -357,6 +357,23 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
                   "Check for repeated observations (or other perfect linear combinations in X).");
   BK_REQUIRE(lastkeeper > 0, "fit: no eigenpair passes the eigtrunc threshold");
   const int64_t k = lastkeeper;
+  if (getenv("BIGKRLS_VERBOSE")) {
+    // (diagnostic: what every rank holds after the decomposition -- equal lines on all ranks -- and Q'Q of the first and
+    //  last kept columns; a column with a non-finite entry shows as nan)
+    long double sv = 0.0L;
+    for (int64_t i = 0; i < k; ++i) sv += vals[i];
+    double g[2] = {0.0, 0.0};
+    void* pg = nullptr;
+    if (ws_get(ctx, SLOT_COMM_SMALL, 64 * sizeof(double), &pg) == BIGKRLS_OK) {
+      double* dg = (double*)pg;
+      (void)gemm(ctx, 1, 0, 1, 1, n, 1.0, dQ, n, dQ, n, 0.0, dg, 1);
+      (void)gemm(ctx, 1, 0, 1, 1, n, 1.0, dQ + (k - 1) * n, n, dQ + (k - 1) * n, n, 0.0, dg + 1, 1);
+      PinnedFetch pf(ctx, 2);
+      if (pf.add(g, dg, 2 * sizeof(double)) == BIGKRLS_OK) (void)pf.finish();
+    }
+    fprintf(stderr, "[bigkrls] fit: rank %d kept %lld, sum(vals[:k]) = %.17g, vals[0] = %.17g, vals[k-1] = %.17g, |q_0|^2 = %.15g, |q_k-1|^2 = %.15g\n",
+            comm ? comm->rank : 0, (long long)k, (double)sv, vals[0], vals[k - 1], g[0], g[1]);
+  }
   timer.mark();                                                           // eigen
 
   // ---- step 3: lambda (:271-278; `tol` is never forwarded by the reference: 1e-3 n) -----------------

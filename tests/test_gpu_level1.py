@@ -360,9 +360,8 @@ def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, ne
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbytes", [1, 8, 65535, 65536 * 2 + 8, (16 << 20) * 2, (16 << 20) * 5 + 24])
-def test_c_abi_host_copies_are_staged_in_pieces(lib, ctx, nbytes):
-    """bigkrls_h2d / bigkrls_d2h copy caller memory through two pinned halves (64 KB ... 16 MB each, csrc/capi.hip
-    staged_copy): sizes below one half, of exactly two halves, and of several pieces with a ragged tail, byte for byte."""
+def test_c_abi_host_copies_round_trip(lib, ctx, nbytes):
+    """bigkrls_h2d / bigkrls_d2h with caller (pageable) memory: from one byte to 80 MB + 24, byte for byte."""
     import ctypes as C
     rng = np.random.default_rng(nbytes % 1000)
     src = rng.integers(0, 256, size=nbytes, dtype=np.uint8)

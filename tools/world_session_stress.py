@@ -10,6 +10,8 @@ bad = 0
 for r in range(rounds):
     procs = {}
     for name, args in WORLD_CASES.items():
+        if os.environ.get("STRESS_ALL_MOCK") and "--rccl-mock" not in args and "--fault-rank" not in args:
+            args = list(args) + ["--rccl-mock"]          # every case through the RCCL code path (tests/mock_rccl)
         env = dict(os.environ, BIGKRLS_PQ="steps", BIGKRLS_BC="wavefront", BIGKRLS_VERBOSE="1")
         if "--default-knobs" in args:
             env = dict(os.environ, BIGKRLS_VERBOSE="1")
