@@ -28,7 +28,12 @@ def launcher():
     args = [a for a in sys.argv[1:]]
     pos = [a for a in args if a.isdigit()][:3]
     world = int(pos[2]) if len(pos) > 2 else 2
-    port = str(29600 + os.getpid() % 200)
+    # a port of its own (a scheme by PID collides when thread IDs -- the same number space -- push the launchers' PIDs
+    # a multiple of the table size apart)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
