@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="route a single-GPU run through the row-block path (bigkrls_amd.dist) under an RCCL group "
                          "of size 1: exercises exactly the code of --gpus N > 1 on one GPU")
+    ap.add_argument("--long-json", action="store_true",
+                    help="every roofline / other_kernels entry with its definition (`note`) and per-launch figures")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the --gpus N rank processes, let them rendezvous over gloo on the CPU and build the "
                          "library's rank objects over host buffers -- no GPU, no fit: checks the launch path only")
@@ -187,16 +189,12 @@ class CpuBaseline:
                 "value": d["literal_s"],
                 "extrapolated": bool(ex),
                 "efficient_port_s": d["efficient_s"],
-                "sample": (f"literal restatement of the reference at the bench size N={self.n}, P={self.p} "
-                           f"(BLAS/LAPACK threads = {cores}: the thread cap of numpy/scipy's bundled OpenBLAS on this "
-                           f"{host_cpus}-CPU host; hand loops single-threaded like the reference), timed IN FULL: kernel "
-                           "row loop, dsyevd, V, V_yhat = crossprod(K, V K) (4N^3), "
-                           f"{lam_ph.get('probes_timed', 1)} of the {d['probes']} literal solveforc probes of the lambda "
-                           f"search and {der_ph.get('columns_timed', 1)} of the P={self.p} literal derivative columns "
-                           "(each with its 4N^3 term L'VL), as many as the --cpu-budget-s allowed; the untimed probes and "
-                           f"columns enter at the mean of the timed ones: {ex_s:.0f} s = "
-                           f"{100.0 * ex_s / max(d['literal_s'], 1e-9):.0f} % of `value` is scaled, the rest and "
-                           f"efficient_port_s (the O(N^2 K) identities at N={self.n}) are measured in full"),
+                "sample": (f"literal restatement of the reference at N={self.n}, P={self.p}, {cores} BLAS threads on a "
+                           f"{host_cpus}-CPU host (hand loops single-threaded like the reference); timed in full: kernel, "
+                           f"dsyevd, V, V_yhat (4N^3), {lam_ph.get('probes_timed', 1)} of {d['probes']} solveforc probes, "
+                           f"{der_ph.get('columns_timed', 1)} of {self.p} derivative columns (the rest at their mean: "
+                           f"{100.0 * ex_s / max(d['literal_s'], 1e-9):.0f} % of value); efficient_port_s = the O(N^2 K) "
+                           "identities, in full"),
                 "phases_s": {k: ph[k]["s"] for k in lit_keys if k in ph},
                 "extrapolated_phases": ex, "extrapolated_share": round(ex_s / max(d["literal_s"], 1e-9), 3),
                 "host_cpus": int(host_cpus),
@@ -219,6 +217,49 @@ class CpuBaseline:
             res["small_sample"] = {"n": small["n"], "literal_s": small["literal_s"],
                                    "efficient_s": small["efficient_s"], "phases_s": small["phases_s"]}
         return res
+
+
+def _short_kernel(name):
+    """`kernel_name<...>` of an entry whose "kernel" field is `name: what it computes` (the long form is --long-json)."""
+    return name.split(":")[0].split(" (")[0].strip()[:64]
+
+
+_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "total_ms_per_fit", "launches_sampled",
+         "launches", "concurrent", "tflops", "hbm_write_gbs", "fit_flops", "fit_frac")
+
+
+def _compact_entry(e):
+    out = {"kernel": _short_kernel(e["kernel"])}
+    out.update({k: e[k] for k in _KEEP if k in e and e[k] is not None or k == "traffic" and k in e})
+    if "parts" in e:
+        out["parts"] = [{"kernel": _short_kernel(q["kernel"]), "frac": q["frac"], "achieved": q["achieved"],
+                         "avg_launch_us": q["avg_launch_us"], "total_ms_per_fit": q["total_ms_per_fit"],
+                         "traffic": q["traffic"]} for q in e["parts"]]
+    return out
+
+
+def compact_line(res):
+    """The one JSON line in its short form (the driver keeps only the tail of stdout): every definition that used to
+    travel as a `note` is in DESIGN.md section 5; `kernel_gemm` -- the GEMM half of BASELINE.json's metric -- sits
+    inside `roofline`. `--long-json` prints the entries with their definitions."""
+    out = {k: v for k, v in res.items() if k not in ("roofline", "other_kernels", "kernel_gemm", "cpu_baseline", "config")}
+    cfg = dict(res["config"])
+    out["config"] = cfg
+    kg = res.get("kernel_gemm")
+    if kg:
+        kg = {k: v for k, v in kg.items() if k != "note"}
+    if res.get("roofline"):
+        out["roofline"] = _compact_entry(res["roofline"])
+        out["roofline"]["kernel_gemm"] = kg
+    out["other_kernels"] = [_compact_entry(e) for e in res.get("other_kernels", [])]
+    cb = res.get("cpu_baseline")
+    if cb:
+        cb = dict(cb)
+        cb.pop("small_sample", None)
+        cb.pop("extrapolated_phases", None)
+        out["cpu_baseline"] = cb
+    out["definitions"] = "DESIGN.md section 5"
+    return out
 
 
 def _free_port():
@@ -412,7 +453,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res if args.long_json else compact_line(res)), flush=True)
     if world > 1 or args.force_dist:
         from bigkrls_amd import dist as bkdist
         bkdist.release_comms()
@@ -616,7 +657,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
             symv_entry(),
             bulge_entry(),
             panel_entry(),
-            mfma_entry("band_update", "syrk_mirror_kernel: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
+            mfma_entry("band_update", "syrk_mirror_kernel<64> at k = 128: A22 -= [V Z][Z V]' on the lower tile triangle + mirrored "
                        "store (stage 1 of the two-stage tridiagonalisation), one launch per 64-column panel",
                        "achieved = m(m+1)*2b algorithmic flops per launch (lower triangle incl. diagonal tiles, "
                        "b = 64, m = trailing size minus the next panel's 64 columns, which the preceding fused "
@@ -709,7 +750,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
         res = {
             # BASELINE.json: "bigKRLS() fit wall-clock + kernel-GEMM fp64 GFLOP/s at N=20000,P=20";
             # `value` is the wall-clock half, `kernel_gemm.gflops` the GEMM half
-            "metric": f"bigKRLS() fit wall-clock at N={n},P={p} (kernel-GEMM fp64 GFLOP/s in kernel_gemm.gflops)",
+            "metric": f"bigKRLS() fit wall-clock at N={n},P={p} (kernel-GEMM fp64 GFLOP/s: roofline.kernel_gemm.gflops)",
             "value": round(sec_per_fit, 4),
             "unit": "s",
             "n_gpus": world,
@@ -726,7 +767,7 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                                     f"Neig={'N' if cfg['neig'] is None else cfg['neig']}, "
                                     f"eigtrunc={cfg['eigtrunc'] if cfg['eigtrunc'] is not None else (0.001 if n > 3000 else 0)}, "
                                     f"{'all derivatives' if cfg['which'] is None else 'which.derivatives=' + str(cfg['which'])}, "
-                                    "vcov.est=TRUE; G(N,P,seed) = sin(X beta)+0.25 eps"),
+                                    "vcov.est=TRUE; synthetic G(N,P,seed)"),
                        "name": cfg["name"], "n": n, "p": p, "seed": cfg["seed"], "neig": cfg["neig"],
                        "which_derivatives": cfg["which"], "lastkeeper": int(lastkeeper),
                        "lambda": float(lam),

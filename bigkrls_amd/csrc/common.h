@@ -156,6 +156,11 @@ enum Slot {
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
+// ---- trace.hip: diagnostic hashes of buffers (BIGKRLS_TRACE_DIR; off otherwise) -----------------
+bool trace_on();
+// hash of `count` doubles (or 8-byte words) at dev_ptr, computed on `st` (synchronised), appended to the process's trace
+int trace_point(bigkrls_ctx* ctx, hipStream_t st, const char* tag, const void* dev_ptr, int64_t count, int64_t extra = 0);
+int trace_host(const char* tag, const void* host_ptr, int64_t count, int64_t extra = 0);
 // Bracket one launch with HIP events when ctx->profile is on: call prof_begin before the
 // launch and prof_end after it; `work` is the launch's algorithmic bytes (or flops).
 int prof_begin(bigkrls_ctx* ctx, const char* name, double work, hipStream_t stream = nullptr);
@@ -297,6 +302,7 @@ int dist_s1_thin(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y);
 int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
                         int64_t row0);
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols);
+int dist_s1_trace(bigkrls_ctx* ctx, int64_t n, int64_t k);   // diagnostics: hashes of panel k's replicated factors
 // several panels per trailing update (the group that starts at k0): see csrc/eigen.hip
 int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0);
 int dist_s1_thin_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, int64_t k0);

@@ -86,38 +86,50 @@ int cb_fail(const char* what, int rc) {
 
 }  // namespace
 
+// BIGKRLS_TRACE_DIR (diagnostics, csrc/trace.hip): hash of what a collective is given and of what it delivers
+static int comm_trace(bigkrls_comm* comm, const char* tag, const double* p, int64_t count, int64_t extra) {
+  if (!trace_on() || !comm->ctx) return BIGKRLS_OK;
+  return trace_point(comm->ctx, comm->ctx->stream, tag, p, count, extra);
+}
+
 int comm_all_reduce(bigkrls_comm* comm, double* dbuf, int64_t count, int op) {
   if (!comm || count <= 0) return BIGKRLS_OK;
+  BK_TRY(comm_trace(comm, "L:ar_in", dbuf, count, op));
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.all_reduce(comm->cb.user, dbuf, count, op);
-    return rc ? cb_fail("all_reduce", rc) : BIGKRLS_OK;
+    if (rc) return cb_fail("all_reduce", rc);
+    return comm_trace(comm, "C:ar_out", dbuf, count, op);
   }
   BK_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclFloat64, op == COMM_MIN ? ncclMin : ncclSum,
                            (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return BIGKRLS_OK;
+  return comm_trace(comm, "C:ar_out", dbuf, count, op);
 }
 
 int comm_all_gather(bigkrls_comm* comm, const double* dsend, double* drecv, int64_t count) {
   if (!comm || count <= 0) return BIGKRLS_OK;
+  BK_TRY(comm_trace(comm, "L:ag_in", dsend, count, 0));
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.all_gather(comm->cb.user, dsend, drecv, count);
-    return rc ? cb_fail("all_gather", rc) : BIGKRLS_OK;
+    if (rc) return cb_fail("all_gather", rc);
+    return comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
   }
   BK_NCCL(rccl().AllGather(dsend, drecv, (size_t)count, ncclFloat64, (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return BIGKRLS_OK;
+  return comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
 }
 
 int comm_broadcast(bigkrls_comm* comm, double* dbuf, int64_t count, int root) {
   if (!comm || count <= 0) return BIGKRLS_OK;
+  BK_TRY(comm_trace(comm, comm->rank == root ? "L:bc_in_root" : "L:bc_in", dbuf, count, root));
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.broadcast(comm->cb.user, dbuf, count, root);
-    return rc ? cb_fail("broadcast", rc) : BIGKRLS_OK;
+    if (rc) return cb_fail("broadcast", rc);
+    return comm_trace(comm, "C:bc_out", dbuf, count, root);
   }
   BK_NCCL(rccl().Broadcast(dbuf, dbuf, (size_t)count, ncclFloat64, root, (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return BIGKRLS_OK;
+  return comm_trace(comm, "C:bc_out", dbuf, count, root);
 }
 
 // the device word(s) and the pinned scratch the status agreement goes through: allocated when the communicator is
@@ -253,6 +265,7 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
       if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, row0, Y, m));
       BK_TRY(comm_all_reduce(comm, Y, m * b, COMM_SUM));
       if (status == BIGKRLS_OK) local(dist_s1_thin_group(ctx, n, k, Y, k0));
+      if (status == BIGKRLS_OK) local(dist_s1_trace(ctx, n, k));
       const int64_t nxt = k + b;
       int64_t first = 0;
       if (has_panel(nxt)) {
@@ -277,6 +290,7 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
     if (status == BIGKRLS_OK) local(dist_s1_av(ctx, n, k, Aact, n, nact, row0, Y, m));
     BK_TRY(comm_all_reduce(comm, Y, m * b, COMM_SUM));
     if (status == BIGKRLS_OK) local(dist_s1_thin(ctx, n, k, Y));
+    if (status == BIGKRLS_OK) local(dist_s1_trace(ctx, n, k));
     const int64_t nxt = k + b;
     int64_t first = 0;                                   // own columns already updated before the look-ahead
     if (has_panel(nxt)) {
@@ -374,6 +388,7 @@ int bigkrls_comm_create(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const vo
   comm->nranks = nranks;
   comm->rank = rank;
   comm->nccl = (void*)c;
+  (void)trace_host("L:comm_rccl", nullptr, 0, (int64_t)rank * 1000 + nranks);
   *out = comm;
   return BIGKRLS_OK;
 }
@@ -391,6 +406,7 @@ int bigkrls_comm_create_callbacks(bigkrls_ctx* ctx, int32_t nranks, int32_t rank
   comm->rank = rank;
   comm->use_cb = true;
   comm->cb = *table;
+  (void)trace_host("L:comm_callbacks", nullptr, 0, (int64_t)rank * 1000 + nranks);
   *out = comm;
   return BIGKRLS_OK;
 }

@@ -2516,6 +2516,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     int blocks = (int)std::min<int64_t>(((int64_t)S2_LD * N + 255) / 256, 8192);
     hipLaunchKernelGGL(s1_extract_band, dim3(blocks), dim3(256), 0, st, (const double*)W, n, AB);
     BK_CHECK_LAUNCH();
+    if (trace_on()) BK_TRY(trace_point(ctx, st, "R:eig_band", AB, (int64_t)S2_LD * N, mode));
     // progress flags / error word of the persistent bulge-chasing kernel: the (unused here)
     // tau and scratch vectors of the one-stage path
     int* bc_err = (int*)scratch;
@@ -2597,6 +2598,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       set_error("eigen: non-finite entries after tridiagonalisation (NaN/Inf in the input?)");
       return BIGKRLS_EINVAL;
     }
+  if (trace_on()) {
+    BK_TRY(trace_host("R:eig_d", hd.data(), n, mode));
+    BK_TRY(trace_host("R:eig_e", he.data(), n - 1, mode));
+  }
   BK_TRY(ws_get(ctx, SLOT_EIG_Q0, N * N * sizeof(double), &pQ0));
   BK_TRY(ws_get(ctx, SLOT_EIG_Q1, N * N * sizeof(double), &pQ1));
   std::vector<double> vals_desc;
@@ -2605,6 +2610,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   BK_TRY(divide_conquer(ctx, n, hd, he, (double*)pQ0, (double*)pQ1, (double*)pU, n_vals,
                         n_vecs_max, keep_thresh, vals_desc, src_cols, &Qfin));
   tick("divide & conquer");
+  if (trace_on()) {
+    BK_TRY(trace_host("R:eig_vals", vals_desc.data(), n_vals, (int64_t)src_cols.size()));
+  }
   BK_HIP(hipMemcpyAsync(vals, vals_desc.data(), n_vals * sizeof(double), hipMemcpyHostToDevice, st));
   const int nv = (int)src_cols.size();
   if (h_n_vecs) *h_n_vecs = nv;
@@ -2650,6 +2658,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   }
   if (bt2_T != nullptr || bt1_V != nullptr)
     BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
+  if (trace_on() && nv > 0 && n_vecs_max > 0) {
+    const int tc0 = (int)((int64_t)nv * part_index / part_count), tc1 = (int)((int64_t)nv * (part_index + 1) / part_count);
+    if (tc1 > tc0 && ldv == N) BK_TRY(trace_point(ctx, st, "L:eig_Qpart", vecs + (int64_t)tc0 * ldv, (int64_t)(tc1 - tc0) * ldv, tc0));
+  }
   if (bt2_err != nullptr) {
     // watchdog word of the persistent stage-2 back-transform: Z is garbage if it fired -> the decomposition is redone
     // with per-wavefront launches (by the caller's replay in the distributed fit)
@@ -2872,6 +2884,18 @@ int dist_s1_update(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, double* Ac
                    int64_t row0) {
   BK_TRY(dist_s1_thin(ctx, n, k, Y));
   return dist_s1_update_cols(ctx, n, k, Acols, lda, ncols, row0);
+}
+
+// diagnostics (BIGKRLS_TRACE_DIR): the replicated factors of panel k -- V, T, tau -- once its factorisation has been consumed
+int dist_s1_trace(bigkrls_ctx* ctx, int64_t n, int64_t k) {
+  if (!trace_on()) return BIGKRLS_OK;
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  BK_TRY(dist_s1_wait_panel(ctx, ds));
+  const int64_t m = n - k - S2_B;
+  BK_TRY(trace_point(ctx, ctx->stream, "R:s1_V", ds->ops.ws.Vp, m * S2_B, k));
+  BK_TRY(trace_point(ctx, ctx->stream, "R:s1_T", ds->ops.Tof((int)k), S2_B * S2_B, k));
+  return trace_point(ctx, ctx->stream, "R:s1_tau", ds->ops.taus1 + k, S2_B, k);
 }
 
 int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int64_t ncols) {

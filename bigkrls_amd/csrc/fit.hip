@@ -259,6 +259,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   double* dQ = (double*)pq;
   double* dK = out->d_K ? out->d_K : (double*)pk;
 
+  if (trace_on()) BK_TRY(trace_host("L:fit_begin", nullptr, 0, n));
   PhaseTimer timer(ctx);
   timer.mark();
   // ---- standardise (R/bigKRLS.R:248-254) straight into the pinned staging buffer, upload ----------
@@ -357,6 +358,10 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
                   "Check for repeated observations (or other perfect linear combinations in X).");
   BK_REQUIRE(lastkeeper > 0, "fit: no eigenpair passes the eigtrunc threshold");
   const int64_t k = lastkeeper;
+  if (trace_on()) {   // diagnostics (csrc/trace.hip): what every rank holds after the decomposition
+    BK_TRY(trace_host("R:fit_vals", vals.data(), neig, k));
+    BK_TRY(trace_point(ctx, st, "R:fit_Q", dQ, n * k, dist_mode));
+  }
   if (getenv("BIGKRLS_VERBOSE")) {
     // (diagnostic: what every rank holds after the decomposition -- equal lines on all ranks -- and Q'Q of the first and
     //  last kept columns; a column with a non-finite entry shows as nan)
@@ -389,6 +394,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     BK_TRY(agreed(own_qty()));
     BK_TRY(comm_all_reduce(comm, da, k, COMM_SUM));
   }
+  if (trace_on()) BK_TRY(trace_point(ctx, st, "R:fit_a", da, k, 0));
   double lambda = opt->lambda;
   int64_t nprobes = 0;
   if (!(lambda > 0.0)) {
@@ -431,6 +437,11 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     BK_TRY(agreed(fetch_c()));              // (the derivative pass below has collectives of its own)
   }
   timer.mark();                                                           // coeffs
+  if (trace_on()) {
+    BK_TRY(trace_host("R:fit_lambda", &lambda, 1, nprobes));
+    BK_TRY(trace_host("R:fit_c", coeffs.data(), n, 0));
+    BK_TRY(trace_host("R:fit_yhat", yhat.data(), n, 0));
+  }
 
   double sigmasq = NaN;
   std::vector<double> wv(k);
@@ -530,6 +541,10 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     std::vector<double> D((size_t)n * pd);
     BK_TRY(download(ctx, D.data(), dD, n * pd, pin));
     timer.mark();                                                         // derivatives
+    if (trace_on()) {
+      BK_TRY(trace_host("R:fit_D", D.data(), n * pd, 0));
+      BK_TRY(trace_host("R:fit_var", var.data(), pd, 0));
+    }
     if (out->derivatives_std) std::memcpy(out->derivatives_std, D.data(), D.size() * sizeof(double));
     if (out->var_avgderivatives_std) std::memcpy(out->var_avgderivatives_std, var.data(), (size_t)pd * sizeof(double));
     // R2AME in standardised units (:390-392)

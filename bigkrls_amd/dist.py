@@ -38,6 +38,20 @@ def _torch_dist():
     return torch, dist
 
 
+def trace_hash(a) -> int:
+    """The 64-bit hash of csrc/trace.hip (sum over the elements of a position-dependent mix of their bits, modulo
+    2^64) of a float64 array: equal to what the library logs for the same bytes on the device."""
+    b = np.ascontiguousarray(a, dtype=np.float64).reshape(-1).view(np.uint64)
+    with np.errstate(over="ignore"):
+        x = b ^ (np.arange(b.size, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return int(x.sum(dtype=np.uint64))
+
+
 def partition(n: int, world: int, align: int = 1):
     """The library's row blocks (csrc/dist.hip, dist_partition): nb = ceil(n / world) rounded up to a multiple of
     `align`; the last ranks may be short or empty."""
@@ -113,6 +127,20 @@ def comm_callbacks(ctx: Optional[Context], group_ops=None) -> Comm:
         else:
             C.memmove(ptr, h.ctypes.data, 8 * h.size)
 
+    # BIGKRLS_TRACE_DIR (diagnostics; the library logs device-side hashes of the same buffers, csrc/trace.hip): the
+    # hash of every buffer as it arrives on the host and as it leaves it, one line per collective
+    trace_dir = os.environ.get("BIGKRLS_TRACE_DIR")
+    trace_state = {"seq": 0, "f": None}
+
+    def trace(kind, count, h_in, h_out):
+        if not trace_dir:
+            return
+        if trace_state["f"] is None:
+            trace_state["f"] = open(os.path.join(trace_dir, f"pid{os.getpid()}.pytrace"), "a")
+        trace_state["f"].write(f"{trace_state['seq']} {kind} {count} {trace_hash(h_in):016x} {trace_hash(h_out):016x}\n")
+        trace_state["f"].flush()
+        trace_state["seq"] += 1
+
     def guard(fn):
         def wrapped(*a):
             try:
@@ -125,9 +153,11 @@ def comm_callbacks(ctx: Optional[Context], group_ops=None) -> Comm:
 
     @guard
     def all_reduce(user, buf, count, op):
-        t = torch.from_numpy(fetch(buf, count))
+        h = fetch(buf, count)
+        t = torch.from_numpy(h.copy() if trace_dir else h)
         if world > 1:
             ops.all_reduce(t, op=ops.ReduceOp.MIN if op == 1 else ops.ReduceOp.SUM)
+        trace("ar", count, h, t.numpy())
         store(buf, t.numpy())
 
     @guard
@@ -138,13 +168,16 @@ def comm_callbacks(ctx: Optional[Context], group_ops=None) -> Comm:
             ops.all_gather_into_tensor(out, t)
         else:
             out.copy_(t)
+        trace("ag", count, t.numpy(), out.numpy())
         store(recv, out.numpy())
 
     @guard
     def broadcast(user, buf, count, root):
-        t = torch.from_numpy(fetch(buf, count))
+        h = fetch(buf, count)
+        t = torch.from_numpy(h.copy() if trace_dir else h)
         if world > 1:
             ops.broadcast(t, src=root)
+        trace("bc", count, h, t.numpy())
         store(buf, t.numpy())
 
     table = _lib.Collectives()
