@@ -189,6 +189,9 @@ class PinnedFetch {
 int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha,
          const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
          int64_t ldc);
+// C (m x n, n <= 48) = A (m x k) B (k x n), both not transposed: the 128 x 48 tile of the marginal-effects pass
+int gemm_nn_skinny48(bigkrls_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                     int64_t ldb, double* C, int64_t ldc);
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,
                  int64_t v, int64_t ldb, int64_t p, double sigma, double* out, int64_t ldo,
                  int64_t diag_shift);

@@ -139,7 +139,12 @@ int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows,
   BK_CHECK_LAUNCH();
   // KB (n_rows x nb) = Krows' (n_rows x n) * B (n x nb). The whole (exactly symmetric) K: K B, the product that
   // streams K along its contiguous dimension (the transposed-operand GEMM runs at about a third of its rate)
-  if (n_rows == n && row0 == 0)
+  // (33 .. 48 operand columns -- P = 16 .. 23 -- on the 128 x 48 tile: the 128 x 64 tile of gemm() would run the MFMA
+  //  units on up to a third of padding; BIGKRLS_DERIV48=0: the generic kernel, for cross-checks)
+  static const bool use48 = [] { const char* e = getenv("BIGKRLS_DERIV48"); return !(e && e[0] == '0'); }();
+  if (n_rows == n && row0 == 0 && nb > 32 && nb <= 48 && n >= 4096 && use48)
+    BK_TRY(gemm_nn_skinny48(ctx, n, nb, n, Krows, ldk, (const double*)pb, n, (double*)pkb, n));
+  else if (n_rows == n && row0 == 0)
     BK_TRY(gemm(ctx, 0, 0, n, nb, n, 1.0, Krows, ldk, (const double*)pb, n, 0.0, (double*)pkb, n));
   else
     BK_TRY(gemm(ctx, 1, 0, n_rows, nb, n, 1.0, Krows, ldk, (const double*)pb, n, 0.0, (double*)pkb,

@@ -551,6 +551,139 @@ int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, doub
 }
 
 // ---------------------------------------------------------------------------
+// Skinny N,N product C (M x N, N <= 48) = A (M x K, m-contiguous) B (K x N): the marginal-effects pass
+// K [1, c, x_j, x_j o c ...] (csrc/deriv.hip), whose 2 + 2P operand columns (42 at P = 20) would pay for 64 in the
+// 128 x 64 tile of gemm_kernel. Tile 128 x 48 x 16, four waves of 32 rows x 48 columns (2 x 3 MFMA tiles each), two
+// k-tiles in flight, split-K into slabs summed by splitk_reduce_kernel in slab order (deterministic).
+// ---------------------------------------------------------------------------
+constexpr int SK_BN = 48;
+constexpr size_t sk48_smem_bytes() { return (size_t)(2 * lds_stage_of(true, BM) + 2 * lds_stage_of(false, SK_BN)) * sizeof(double); }
+__global__ __launch_bounds__(NT, 2) void gemm_nn48_kernel(GemmOperands g, int tiles_m, int k_chunk,
+                                                         double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int A_STAGE = lds_stage_of(true, BM), B_BASE = 2 * A_STAGE, B_STAGE = lds_stage_of(false, SK_BN);
+  constexpr int NJ = SK_BN / 16;
+  const int tm = xcd_remap(blockIdx.x, tiles_m);
+  const int m0 = tm * BM;
+  const int z = blockIdx.y;
+  const int kbeg = z * k_chunk, kend = min(g.K, kbeg + k_chunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave * 32, lm = lane & 15, lk = lane >> 4;
+  d4 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+  const int tid = threadIdx.x;
+  const bool b_fast = g.N >= SK_BN;
+  const double* pa;
+  const double* pb;
+  {
+    const int gx = m0 + tid % BM;
+    pa = g.A + (gx < g.M ? gx : g.M - 1) + (int64_t)(kbeg + tid / BM) * g.lda;
+    pb = g.B + (kbeg + (tid & 15)) + (int64_t)(b_fast ? (tid >> 4) : 0) * g.ldb;
+  }
+  const int64_t sa = (NT / BM) * g.lda, ia = BK * g.lda, sb = 16 * g.ldb;
+  double ra[BM / 16], rb[SK_BN / 16], ra2[BM / 16], rb2[SK_BN / 16];
+  auto load_into = [&](int k0, double (&xa)[BM / 16], double (&xb)[SK_BN / 16]) {
+    const bool full = k0 + BK <= kend;
+    if (full) tile_load_strided<BM>(pa, sa, xa);
+    else tile_load<true, BM>(g.A, g.lda, m0, k0, g.M, kend, xa);
+    if (full && b_fast) tile_load_strided<SK_BN>(pb, sb, xb);
+    else tile_load<false, SK_BN>(g.B, g.ldb, 0, k0, g.N, kend, xb);
+    pa += ia;
+    pb += BK;
+  };
+  auto stage = [&](int k0, int st, double (&xa)[BM / 16], double (&xb)[SK_BN / 16]) {
+    if (k0 + BK > kend) {
+      tile_zero_ktail<true, BM>(k0, kend, xa);
+      tile_zero_ktail<false, SK_BN>(k0, kend, xb);
+    }
+    tile_store<true, BM>(smem + st * A_STAGE, xa);
+    tile_store<false, SK_BN>(smem + B_BASE + st * B_STAGE, xb);
+  };
+  auto mfma_tile = [&](int cur) {
+    const double* as = smem + cur * A_STAGE;
+    const double* bs = smem + B_BASE + cur * B_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[2], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = as[lds_at<true, BM>(kk + lk, wm + i * 16 + lm)];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = bs[lds_at<false, SK_BN>(kk + lk, j * 16 + lm)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (ntiles > 0) {
+    load_into(kbeg, ra, rb);
+    stage(kbeg, 0, ra, rb);
+    if (ntiles > 1) load_into(kbeg + BK, ra2, rb2);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+      if (t + 2 < ntiles) load_into(kbeg + (t + 2) * BK, ra, rb);
+      mfma_tile(0);
+      if (t + 1 < ntiles) stage(kbeg + (t + 1) * BK, 1, ra2, rb2);
+      __syncthreads();
+      if (t + 1 >= ntiles) break;
+      if (t + 3 < ntiles) load_into(kbeg + (t + 3) * BK, ra2, rb2);
+      mfma_tile(1);
+      if (t + 2 < ntiles) stage(kbeg + (t + 2) * BK, 0, ra, rb);
+      __syncthreads();
+    }
+  }
+  double* P = partial + (int64_t)z * g.M * g.N;
+  const int M = g.M, N = g.N;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm + i * 16 + lm, n = j * 16 + lk + 4 * r;
+        if (m < M && n < N) P[(int64_t)m + (int64_t)n * M] = acc[i][j][r];
+      }
+}
+
+int gemm_nn_skinny48(bigkrls_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                     int64_t ldb, double* C, int64_t ldc) {
+  BK_REQUIRE(m > 0 && n > 0 && n <= SK_BN && k > 0 && m < (1ll << 31) && k < (1ll << 31) && A && B && C, "gemm_nn_skinny48: bad arguments");
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)n, (int)k, nullptr};
+  const int tiles_m = (int)((m + BM - 1) / BM);
+  // two workgroups per CU: split K so that the grid fills whole rounds of the 512 slots (or as much of one as K allows)
+  constexpr int resident = 256 * 2;
+  int splits = 1;
+  {
+    const int maxs = (int)std::min<int64_t>(64, std::max<int64_t>(1, k / 256));
+    const double per_split = 3.2e-6 * (double)m * (double)n + 0.2;
+    double best = 1e30;
+    for (int sp = 1; sp <= maxs; ++sp) {
+      const int rounds = (tiles_m * sp + resident - 1) / resident;
+      const double cost = 0.045 * rounds * ((double)k / sp) + per_split * sp;
+      if (cost < best - 1e-9) { best = cost; splits = sp; }
+    }
+  }
+  int k_chunk = (int)(((k + splits - 1) / splits + BK - 1) / BK * BK);
+  splits = (int)((k + k_chunk - 1) / k_chunk);
+  void* p = nullptr;
+  const int slot = (ctx->side_stream && ctx->stream == ctx->side_stream) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
+  BK_TRY(ws_get(ctx, slot, (int64_t)splits * m * n * sizeof(double), &p));
+  BK_TRY(ensure_dyn_smem(ctx, (const void*)gemm_nn48_kernel, sk48_smem_bytes()));
+  hipLaunchKernelGGL(gemm_nn48_kernel, dim3(tiles_m, splits), dim3(NT), sk48_smem_bytes(), ctx->stream, g, tiles_m, k_chunk,
+                     (double*)p);
+  BK_CHECK_LAUNCH();
+  int blocks = (int)std::min<int64_t>((m * n + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)p, splits, (int)m, (int)n,
+                     1.0, 0.0, C, ldc);
+  BK_CHECK_LAUNCH();
+  return BIGKRLS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // symmetric rank-k update of the lower triangle: C(lower) += alpha * A B'
 // (A, B are m x k; used by the tridiagonalisation's trailing update
 //  A22 -= [V W][W V]', whose consumers only ever read the lower triangle).

@@ -237,6 +237,50 @@ def test_derivmat_matches_literal(lib, n, p, binary):
     assert np.max(np.abs(var - var_ref) / np.abs(var_ref)) < 1e-8
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p", [(4200, 16), (4500, 20), (4301, 23)])
+def test_deriv_rows_on_the_48_wide_tile(n, p):
+    """The one pass over K for all columns, K [1, c, x_j, x_j o c | b_j, b_j o c] (src/bigderiv_v3.cpp:90-106 in O(N^2)),
+    on the 128 x 48 tile that 33..48 operand columns (P = 16..23) take at n >= 4096: against the same products in
+    numpy (the generic 128 x 64 kernel covers every other column count: test_derivmat_matches_literal, the C2 fit)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops, _lib
+    ctx = bk.Context(0)
+    rng = np.random.default_rng(31)
+    X = rng.standard_normal((n, p))
+    X[:, p - 1] = (X[:, p - 1] > 0.12345).astype(float)              # a binary column: first differences (:31-87)
+    c = rng.standard_normal(n) / n
+    sigma = float(p)
+    dX = ctx.from_numpy(X)
+    K = ops.bGaussKernel(dX, sigma)
+    Kh = K.to_numpy()
+    dc = ctx.from_numpy(c.reshape(n, 1))
+    isb = np.zeros(p, dtype=np.int32)
+    isb[p - 1] = 1
+    D, S = ctx.empty(n, p), ctx.empty(n, p)
+    _lib.call("bigkrls_dev_deriv_rows", ctx.handle, K.ptr, n, n, K.ld, 0, dX.ptr, p, dX.ld, isb.ctypes.data, dc.ptr, sigma,
+              D.ptr, D.ld, S.ptr, S.ld)
+    Dh, Sh = D.to_numpy(), S.to_numpy()
+    K1, Kc = Kh.sum(axis=1), Kh @ c
+    for j in range(p - 1):                                           # continuous columns (:103, :105)
+        x = X[:, j]
+        d_ref = (-2.0 / sigma) * (x * Kc - Kh @ (x * c))
+        s_ref = x * K1 - Kh @ x
+        assert np.max(np.abs(Dh[:, j] - d_ref)) < 1e-12 * max(1.0, np.max(np.abs(d_ref)))
+        assert np.max(np.abs(Sh[:, j] - s_ref)) < 1e-11 * max(1.0, np.max(np.abs(s_ref)))
+    # the binary column: the group sums of :60-71
+    b = X[:, p - 1]
+    hi = b == b.max()
+    sd = 1.0 / (b.max() - b.min())
+    phi = -1.0 / (sd * sd * sigma)
+    E, Einv = np.exp(phi), np.exp(-phi)
+    Kb, Kbc = Kh @ hi.astype(float), Kh @ (hi * c)
+    Sc = np.where(hi, Kbc, Kc - Kbc)
+    Oc = np.where(hi, Kc - Kbc, Kbc)
+    d_ref = sd * np.where(hi, 1.0, -1.0) * ((1.0 - E) * Sc + (1.0 - Einv) * Oc)
+    assert np.max(np.abs(Dh[:, p - 1] - d_ref)) < 1e-12 * max(1.0, np.max(np.abs(d_ref)))
+
+
 def test_error_reporting(lib):
     st = lib.bigkrls_gauss_kernel(None, 10, 2, 1.0, None)
     assert st == 1 and b"gauss_kernel" in lib.bigkrls_last_error()
