@@ -121,6 +121,7 @@ SIGNATURES = {
     "bigkrls_comm_create": [vp, i32, i32, vp, C.POINTER(vp)],
     "bigkrls_comm_create_callbacks": [vp, i32, i32, vp, C.POINTER(vp)],
     "bigkrls_comm_destroy": [vp],
+    "bigkrls_comm_forget_context": [vp],
     "bigkrls_comm_rank": [vp, pi32, pi32],
     "bigkrls_comm_check": [vp, vp, i64],
     "bigkrls_fit_dist_rows": [vp, i64, C.POINTER(FitOptions), pi64, pi64],

@@ -308,6 +308,8 @@ int dist_s1_put(bigkrls_ctx* ctx, int64_t n, int64_t k, const double* strip, int
 int dist_s1_trace(bigkrls_ctx* ctx, int64_t n, int64_t k);   // diagnostics: hashes of panel k's replicated factors
 // several panels per trailing update (the group that starts at k0): see csrc/eigen.hip
 int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0);
+int dist_s1_local_agg_mode(bigkrls_ctx* ctx, int64_t n);            // 4 / 2 / 0: what this rank's settings allow
+int dist_s1_set_agg_mode(bigkrls_ctx* ctx, int64_t n, int mode);    // ... and what the ranks agreed on (their minimum)
 int dist_s1_thin_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Y, int64_t k0);
 int dist_s1_update_cols_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, int64_t lda, int64_t ncols,
                               int64_t row0, int64_t k0, int nblk);

@@ -230,6 +230,13 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
   const int64_t ncl = c1 - c0;
   int live = comm_agree(comm, dist_s1_open(ctx, n));
   BK_TRY(live);
+  {
+    // panels per trailing update: derived from rank-local state (environment, workspace), and it decides the sequence
+    // of collectives below -- every rank runs the schedule of the most restrictive one
+    double mode = (double)dist_s1_local_agg_mode(ctx, n);
+    BK_TRY(comm_all_reduce_host(comm, &mode, 1, COMM_MIN));
+    BK_TRY(dist_s1_set_agg_mode(ctx, n, (int)mode));
+  }
   void* pm = nullptr;
   // strip (n x 64), Y (n x 64)
   BK_TRY(comm_agree(comm, ws_get(ctx, SLOT_DIST_MISC, 2 * n * b * sizeof(double), &pm)));
@@ -418,6 +425,12 @@ int bigkrls_comm_destroy(bigkrls_comm* comm) {
     (void)rccl().CommDestroy((ncclComm_t)comm->nccl);
   }
   delete comm;
+  return BIGKRLS_OK;
+}
+
+int bigkrls_comm_forget_context(bigkrls_comm* comm) {
+  BK_REQUIRE(comm, "comm_forget_context: null communicator");
+  comm->ctx = nullptr;
   return BIGKRLS_OK;
 }
 

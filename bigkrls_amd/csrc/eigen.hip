@@ -2307,6 +2307,7 @@ struct DistS1 {
   S1Ops ops;
   int n = 0;
   bool panel_pending = false;   // a panel factorisation is running on the look-ahead stream (ev_join marks its end)
+  int agg_mode = 0;             // panels per trailing update the ranks agreed on: 4 (groups of four, then pairs), 2 (pairs), 0 (none)
 };
 
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
@@ -2818,11 +2819,25 @@ int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, i
 //      panels is applied after its last panel; panel j's product with the stale column blocks is corrected with the j
 //      pending blocks of the group, as in stage1_to_band) -------------------------------------------------------------
 // size of the group that may start at panel k0: 4 (trailing matrix >= 12 800 rows), 2 (>= 10 752), or 0
-int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0) {
+// what THIS rank would do (its environment, its workspace): the ranks take the minimum (dist_s1_set_agg_mode) -- the
+// group size decides the sequence of collectives, so it must be the same everywhere
+int dist_s1_local_agg_mode(bigkrls_ctx* ctx, int64_t n) {
   DistS1* ds = nullptr;
   if (dist_state(ctx, n, &ds) != BIGKRLS_OK || ds->ops.ws.aggPZ1[0] == nullptr || !ds->ops.fused_small) return 0;
-  static const int env = [] { const char* e = getenv("BIGKRLS_S1AGG"); return e ? atoi(e) : -1; }();
-  if (env == 0) return 0;
+  const char* e = getenv("BIGKRLS_S1AGG");     // read per decomposition, like the single-GPU loop
+  const int env = e ? atoi(e) : -1;
+  return env == 0 ? 0 : (env == 2 ? 2 : 4);
+}
+int dist_s1_set_agg_mode(bigkrls_ctx* ctx, int64_t n, int mode) {
+  DistS1* ds = nullptr;
+  BK_TRY(dist_state(ctx, n, &ds));
+  ds->agg_mode = mode;
+  return BIGKRLS_OK;
+}
+int dist_s1_group_size(bigkrls_ctx* ctx, int64_t n, int64_t k0) {
+  DistS1* ds = nullptr;
+  if (dist_state(ctx, n, &ds) != BIGKRLS_OK || ds->agg_mode == 0) return 0;
+  const int env = ds->agg_mode == 2 ? 2 : -1;
   const int b = S2_B;
   auto panels = [&](int g) {
     for (int j = 0; j < g; ++j)

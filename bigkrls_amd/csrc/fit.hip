@@ -297,11 +297,15 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     // K[:, r0:r1) is untouched, so the replay starts from a fresh copy (the single-GPU eigen() does the same).
     int rc_e = BIGKRLS_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
+      // (a failed copy is a local failure like any other: agreed on before the peers enter the decomposition's first
+      //  collective, not returned from here while they wait in it)
+      int rc_copy = BIGKRLS_OK;
       if (nloc > 0 && hipMemcpyAsync(pa, dK, (size_t)(n * nloc) * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-        ctx->no_resident = false;
         set_error("fit: copy of the column block of K failed");
-        return BIGKRLS_EHIP;
+        rc_copy = BIGKRLS_EHIP;
       }
+      rc_e = comm_agree(comm, rc_copy);
+      if (rc_e != BIGKRLS_OK) break;
       rc_e = eigen_dense_dist(comm, (double*)pa, n, nb, neig, eigtrunc, dvals, dQ, &lastkeeper);
       if (rc_e != BK_EWATCHDOG || attempt == 1 || ctx->no_resident) break;
       if (getenv("BIGKRLS_VERBOSE"))

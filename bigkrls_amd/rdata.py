@@ -65,7 +65,9 @@ class RVec:
 
 
 class Pairlist(list):
-    """[(tag-or-None, value), ...]"""
+    """[(tag-or-None, value), ...]; `dotted_tail` holds the CDR of the last cell when it is not NULL (a dotted pair:
+    what R's ALTREP classes serialise their state as, CONS(x, metadata))"""
+    dotted_tail = None
 
 
 # ---------------------------------------------------------------------------------------------------- writer
@@ -179,8 +181,9 @@ class _Reader:
         b = self.take(n)
         return b.decode("latin-1" if flags & (0x04 << 12) else "utf-8")
 
-    def item(self):
-        flags = struct.unpack(">I", self.take(4))[0]
+    def item(self, flags: Optional[int] = None):
+        if flags is None:
+            flags = struct.unpack(">I", self.take(4))[0]
         t = flags & 0xFF
         if t == NILVALUE_SXP or t == NILSXP:
             return None
@@ -207,7 +210,11 @@ class _Reader:
                 if flags & 0xFF in (NILVALUE_SXP, NILSXP):
                     return items
                 if flags & 0xFF != LISTSXP:
-                    raise ValueError("dotted pairlists are not supported")
+                    # a dotted pair: the CDR is an ordinary item whose flags have just been read (R writes the CDR of
+                    # a cell by a tail call of WriteItem, src/main/serialize.c) -- the state of wrap_* and
+                    # deferred_string ALTREP objects is CONS(x, <integer metadata>)
+                    items.dotted_tail = self.item(flags)
+                    return items
         if t == CHARSXP:
             return self.charsxp(flags)
         if t == ALTREP_SXP:
@@ -243,12 +250,12 @@ def _altrep(self, flags: int):
         if cls == "compact_intseq":
             return RVec("int", seq.astype(np.int32), attrs)
         return RVec("real", seq, attrs)
-    if cls.startswith("wrap_"):                       # state = list(x, metadata): the wrapped vector itself
+    if cls.startswith("wrap_"):                       # state = CONS(x, metadata) (a dotted pair): the wrapped vector itself
         inner = state.values[0] if isinstance(state, RVec) else state[0][1]
         if isinstance(inner, RVec):
             return RVec(inner.kind, inner.values, inner.attrs + attrs)
         return inner
-    if cls == "deferred_string":                      # as.character(<integer or real vector>), not yet expanded
+    if cls == "deferred_string":                      # state = CONS(arg, scipen): as.character(<integer or real vector>), not yet expanded
         arg = state[0][1] if isinstance(state, Pairlist) else state
         if isinstance(arg, RVec) and arg.kind == "int":
             vals = [None if int(v) == NA_INT else str(int(v)) for v in arg.values]

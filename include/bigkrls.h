@@ -381,6 +381,9 @@ typedef struct bigkrls_collectives {
 int bigkrls_comm_create_callbacks(bigkrls_ctx* ctx, int32_t nranks, int32_t rank, const bigkrls_collectives* table,
                                   bigkrls_comm** comm);
 int bigkrls_comm_destroy(bigkrls_comm* comm);
+/* For hosts whose finalisers run in no particular order (R at exit: r-shim/src/bigkrls_shim.cpp): tell a communicator
+ * that its context has ALREADY been destroyed, so that bigkrls_comm_destroy does not synchronise that context's stream. */
+int bigkrls_comm_forget_context(bigkrls_comm* comm);
 int bigkrls_comm_rank(bigkrls_comm* comm, int32_t* rank, int32_t* nranks);
 /* Plumbing check: one all-reduce (sum) of buf[0 .. count), one all-reduce (min) of buf[count .. 2 count), one
  * all-gather of buf[2 count .. 3 count) into buf[4 count .. (4 + nranks) count) and one broadcast from the last rank

@@ -31,8 +31,16 @@ static inline bigkrls_comm* comm_of(SEXP s) { return handle<bigkrls_comm>(s, "th
 static inline double* dev_or_null(SEXP s) { return Rf_isNull(s) ? nullptr : (double*)R_ExternalPtrAddr(s); }
 static void ctx_finalizer(SEXP s) {
   if (void* p = R_ExternalPtrAddr(s)) { bigkrls_ctx_destroy((bigkrls_ctx*)p); R_ClearExternalPtr(s); } }
+// (finalisers run in no particular order at exit, or when context and communicator become unreachable together: if
+//  the context -- kept in the `prot` slot -- has gone first, the communicator must not touch its stream)
 static void comm_finalizer(SEXP s) {
-  if (void* p = R_ExternalPtrAddr(s)) { bigkrls_comm_destroy((bigkrls_comm*)p); R_ClearExternalPtr(s); } }
+  if (void* p = R_ExternalPtrAddr(s)) {
+    SEXP ctx = R_ExternalPtrProtected(s);
+    if (!(TYPEOF(ctx) == EXTPTRSXP && R_ExternalPtrAddr(ctx))) bigkrls_comm_forget_context((bigkrls_comm*)p);
+    bigkrls_comm_destroy((bigkrls_comm*)p);
+    R_ClearExternalPtr(s);
+  }
+}
 // a device matrix keeps its context alive (the `prot` slot of the external pointer) and is freed through it
 static void dev_finalizer(SEXP s) {
   void* p = R_ExternalPtrAddr(s);

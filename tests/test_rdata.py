@@ -163,17 +163,26 @@ def test_reader_accepts_version_3_rdata_and_expands_altrep():
         return flags(rdata.ALTREP_SXP) + info(cls, "base", typ) + state + nil
 
     seq = altrep("compact_intseq", rdata.INTSXP, real([5, 1, 1]))
-    wrapped = altrep("wrap_real", rdata.REALSXP,
-                     flags(rdata.VECSXP) + struct.pack(">i", 2) + real([0.5, 2.25]) + intv([0, 0]))
+    # the state of wrap_* is CONS(x, metadata), a DOTTED pair (wrapper_Serialized_state, src/main/altclasses.c): one
+    # LISTSXP cell whose CDR is the integer vector itself -- no terminating NULL
+    wrapped = altrep("wrap_real", rdata.REALSXP, flags(rdata.LISTSXP) + real([0.5, 2.25]) + intv([0, 0]))
     # (the second and third items refer back to the symbols 'base' etc. only in R's own output; separate streams
     #  here keep the reference table out of the way)
     o = rdata.unserialize(_v3_stream(seq, False))
     assert o.kind == "int" and o.values.tolist() == [1, 2, 3, 4, 5]
     o = rdata.unserialize(_v3_stream(wrapped, False))
     assert o.kind == "real" and o.values.tolist() == [0.5, 2.25]
-    deferred = altrep("deferred_string", rdata.STRSXP, flags(rdata.LISTSXP) + intv([3, 10]) + flags(rdata.LISTSXP) + intv([0]) + nil)
+    # deferred_string: CONS(arg, scipen), dotted likewise (deferred_string_Serialized_state)
+    deferred = altrep("deferred_string", rdata.STRSXP, flags(rdata.LISTSXP) + intv([3, 10]) + intv([0]))
     o = rdata.unserialize(_v3_stream(deferred, False))
     assert o.kind == "str" and o.values == ["3", "10"]
+    # (the layouts an earlier version of this test pinned -- a VECSXP(2) / a proper two-cell pairlist -- still parse)
+    o = rdata.unserialize(_v3_stream(altrep("wrap_real", rdata.REALSXP, flags(rdata.VECSXP) + struct.pack(">i", 2) +
+                                            real([0.5, 2.25]) + intv([0, 0])), False))
+    assert o.values.tolist() == [0.5, 2.25]
+    # a dotted pair outside ALTREP keeps its tail
+    pl = rdata.unserialize(_v3_stream(flags(rdata.LISTSXP) + real([1.0]) + intv([7]), False))
+    assert isinstance(pl, rdata.Pairlist) and pl[0][1].values.tolist() == [1.0] and pl.dotted_tail.values.tolist() == [7]
     # an .RData file: RDX3 magic + a tagged pairlist
     body = flags(rdata.LISTSXP | rdata.HAS_TAG) + sym("folds") + seq + nil
     pl = rdata.unserialize(gzip.compress(_v3_stream(body, True)))
