@@ -912,6 +912,13 @@ __global__ void dc_lazy_rotate(const MergeDesc* __restrict__ descs, const int* _
   }
 }
 
+#ifdef BK_FAULT_INJECT
+// test build only: keeps the stream busy for `ticks` of the 100 MHz clock, so that what is queued behind it executes late
+__global__ void dc_fault_spin(long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while ((long long)(wall_clock64() - t0) < ticks) {}
+}
+#endif
 __global__ void dc_iota(int* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -1380,6 +1387,14 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     // eigenvector update
     int maxKneed = 0;
     for (int q = 0; q < nm; ++q) maxKneed = std::max(maxKneed, descs[q].Kneed);
+    // Descriptors of this level's batched products. Declared HERE, not inside the branch that fills them: the vector is
+    // the source of an asynchronous host -> device copy, and the runtime reads a pageable source of more than a few KB
+    // when the copy EXECUTES on the stream (it pins the user pages; tools/pageable_h2d_probe.hip), not when
+    // hipMemcpyAsync returns -- so it has to stay alive and untouched until the synchronisation at the end of the level.
+    // (Round 5: it used to be a local of that branch, freed before the synchronisation. With the stream running late --
+    // many processes on one GPU -- the copy then read freed heap memory: garbage descriptors, a wrong eigenvector block
+    // at one level, wrong eigenvalues above it, no error. DESIGN.md section 7.)
+    std::vector<GemmDesc> gd;
     if (maxKneed > 0) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
@@ -1444,7 +1459,6 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         }
       }
     } else if (maxKneed > 0) {
-      std::vector<GemmDesc> gd;
       gd.reserve(2 * nm);
       int gm = 0, gn = 0;
       for (int q = 0; q < nm; ++q) {
@@ -1467,8 +1481,26 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         gm = std::max(gm, std::max(md.n1, n2));
         gn = std::max(gn, md.Kneed);
       }
+#ifdef BK_FAULT_INJECT
+      // BIGKRLS_FAULT=dc_lag (test build): the stream runs 2 ms behind the host, as it does with many processes on one
+      // GPU -- the copy below executes long after hipMemcpyAsync has returned. =dc_gd_clobber additionally overwrites
+      // the descriptors right after the launch (what freeing them early amounted to): the level then goes WRONG, which
+      // is how tools/dc_async_source_probe.py shows that the source is read when the copy executes.
+      const char* dc_fault = getenv("BIGKRLS_FAULT");
+      const bool dc_lag = dc_fault && (std::string(dc_fault) == "dc_lag" || std::string(dc_fault) == "dc_gd_clobber");
+      if (dc_lag) hipLaunchKernelGGL(dc_fault_spin, dim3(1), dim3(64), 0, st, 200000LL);
+#endif
       BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
       BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, gn));
+#ifdef BK_FAULT_INJECT
+      if (dc_fault && std::string(dc_fault) == "dc_gd_clobber") std::memset((void*)gd.data(), 0, gd.size() * sizeof(GemmDesc));
+      if (dc_lag) {   // heap churn: blocks of the descriptors' size, zero-filled and freed (lands on anything freed too early)
+        for (int rep = 0; rep < 4; ++rep) {
+          std::vector<char> junk(gd.size() * sizeof(GemmDesc) + 16, 0);
+          asm volatile("" ::"r"(junk.data()) : "memory");
+        }
+      }
+#endif
     }
     if (max_ndef > 0 && !lazy_level) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
@@ -1479,7 +1511,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       }
       BK_CHECK_LAUNCH();
     }
-    // host vectors (gd, descs) must outlive the async copies
+    // host vectors (gd, descs, A.*) are sources of asynchronous copies: alive and unmodified up to here
     BK_HIP(hipStreamSynchronize(st));
     if (!lazy_level) std::swap(Qc, Qn);
     lap(4);

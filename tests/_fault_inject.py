@@ -4,7 +4,8 @@ Run as a script by tests/test_gpu_configs.py: the library path is per process.
 BIGKRLS_FAULT=watchdog: the first attempt reports a fired persistent-kernel watchdog after stage 1; the call must
 redo the decomposition with the per-step kernels and succeed. BIGKRLS_FAULT=noconv: the block Lanczos reports
 non-convergence; the same call must fall through to the dense path (no user-visible switch, like the reference's
-eigs_sym branch, src/eigen.cpp:18-22)."""
+eigs_sym branch, src/eigen.cpp:18-22). BIGKRLS_FAULT=dc_lag: the stream lags behind the host inside the divide &
+conquer; the result must not change by a bit."""
 import os
 import sys
 
@@ -47,6 +48,17 @@ third = ops.bEigen(K, 40, -1.0)
 assert rel(third.values, good.values) < 1e-12
 res, orth = quality(K, third.vectors, third.values)
 assert res < 1e-11 and orth < 1e-11, (res, orth)
+# BIGKRLS_FAULT=dc_lag: the stream runs 2 ms behind the host inside the divide & conquer (a spin kernel ahead of each
+# level's descriptor upload) while the host churns its heap: every host vector that is the source of an asynchronous
+# copy must stay alive and untouched until the level is synchronised. (The regression of round 5: one of them was
+# freed early and a late copy read garbage -- wrong eigenvalues, no error.) All eigenvectors: the explicit merges.
+os.environ["BIGKRLS_FAULT"] = ""
+full = ops.bEigen(K, None, -1.0)
+os.environ["BIGKRLS_FAULT"] = "dc_lag"
+for _ in range(2):
+    lag = ops.bEigen(K, None, -1.0)
+    assert np.array_equal(np.asarray(lag.values), np.asarray(full.values))
+    assert np.array_equal(lag.vectors.to_numpy(), full.vectors.to_numpy())
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)

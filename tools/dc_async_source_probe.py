@@ -1,0 +1,31 @@
+"""Shows on the device what the divide & conquer's round-5 bug relied on NOT happening: with the stream running late,
+a pageable host vector that is the source of hipMemcpyAsync is read when the copy EXECUTES. Test build of the library,
+BIGKRLS_FAULT=dc_gd_clobber: a spin kernel keeps the stream 2 ms behind, the descriptor vector of each level's batched
+product is zeroed right after the launch (what freeing it early amounted to once the heap block was reused). If the
+runtime had taken its copy when hipMemcpyAsync returned, the result would be unchanged.
+    python tools/dc_async_source_probe.py"""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import numpy as np
+import bigkrls_amd._lib as L
+L.LIB_PATH = os.path.join(ROOT, "tests", "capi", "libbigkrls_hip_fault.so")
+import bigkrls_amd as bk
+from bigkrls_amd import ops
+from bigkrls_amd.synth import synth
+ctx = bk.Context(0)
+n, p = 3000, 5
+X, _ = synth(n, p, 9)
+K = ops.bGaussKernel(ctx.from_numpy((X - X.mean(0)) / X.std(0, ddof=1)), float(p))
+good = ops.bEigen(K, None, -1.0)
+for mode in ("dc_lag", "dc_gd_clobber"):
+    os.environ["BIGKRLS_FAULT"] = mode
+    try:
+        e = ops.bEigen(K, None, -1.0)
+        dv = float(np.max(np.abs(np.asarray(e.values) - np.asarray(good.values))) / abs(good.values[0]))
+        Q = e.vectors.to_numpy()
+        orth = float(np.max(np.abs(Q.T @ Q - np.eye(Q.shape[1]))))
+        print(f"BIGKRLS_FAULT={mode}: eigenvalues differ from the undisturbed run by {dv:.3e} (relative), |Q'Q - I| = {orth:.3e}, "
+              f"kept {e.lastkeeper} vs {good.lastkeeper}")
+    except Exception as ex:
+        print(f"BIGKRLS_FAULT={mode}: {type(ex).__name__}: {str(ex)[:200]}")
