@@ -96,6 +96,17 @@ int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap, int thread
 
 int side_stream_get(bigkrls_ctx* ctx) {
   if (!ctx->side_stream) {
+    // BIGKRLS_NO_SIDE=1 (diagnostics): no second stream -- the "look-ahead" work is queued on the main stream, every
+    // fork / join becomes a no-op. Slower; separates cross-stream ordering from everything else when hunting a
+    // nondeterminism (tools/oversub_single.py --arms).
+    if (getenv("BIGKRLS_NO_SIDE")) {
+      ctx->side_stream = ctx->stream;
+      ctx->side_is_main = true;
+      BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+      BK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+      return BIGKRLS_OK;
+    }
     // highest priority: its short latency-bound launches must not queue behind the thousands of
     // workgroups of the throughput kernel they overlap with
     int prio_lo = 0, prio_hi = 0;
@@ -285,7 +296,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
-  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->side_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);

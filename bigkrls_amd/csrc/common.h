@@ -59,6 +59,7 @@ struct bigkrls_ctx {
   void* dist_s1 = nullptr;
   void (*dist_s1_free)(void*) = nullptr;
   hipStream_t side_stream = nullptr;
+  bool side_is_main = false;   // BIGKRLS_NO_SIDE (diagnostics): side_stream is the main stream itself
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
   static constexpr int kSlots = 48;

@@ -280,6 +280,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   if (!comm) BK_TRY(kernel_block(ctx, dX, n, n, dX, n, n, p, sigma, dK, n, 0));
   else BK_TRY(agreed(nloc > 0 ? kernel_block(ctx, dX, n, n, dX + r0, nloc, n, p, sigma, dK, n, r0) : BIGKRLS_OK));   // K[:, r0:r1): no exchange
   timer.mark();                                                           // kernel
+  if (trace_on()) BK_TRY(trace_point(ctx, st, "L:fit_K", dK, n * std::max<int64_t>(nloc, 1), r0));
 
   // ---- step 2: eigen (:266-269; bEigen's lastkeeper rule on the device side) ------------------------
   int64_t lastkeeper = 0;

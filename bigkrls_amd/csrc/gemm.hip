@@ -1696,14 +1696,16 @@ static int kb_band_rows(int64_t p, int tiles) {
 }
 
 // Non-temporal stores of the output tiles (the wave kernels; the workgroup-tiled kernel always uses them): the 8 N^2
-// bytes of K pass through the write-back L2s and evict the rows of X the tiles are built from. While X fits an XCD's
-// 4 MB L2 beside the output stream that costs nothing and ordinary stores are 6 % faster (N = 20 000, P = 20: 0.730 vs
-// 0.775 ms); above, the re-fetches stall the waves and non-temporal stores are 13 % faster (N = 50 000: 4.80 -> 4.24 ms,
-// 4.17 -> 4.71 TB/s written). BIGKRLS_KB_NT=0|1 overrides.
+// bytes of K pass through the write-back L2s and evict the rows of X the tiles are built from; with X larger than an
+// XCD's 4 MB L2 the re-fetches stall the waves and non-temporal stores are 13 % faster (N = 50 000: 4.80 -> 4.24 ms,
+// 4.17 -> 4.71 TB/s written). At N = 20 000, P = 20 (X = 3.2 MB) a loop over the launch alone prefers ordinary stores
+// (0.730 vs 0.775 ms, round 4), but INSIDE the fit -- cold caches, the launch once per fit -- non-temporal stores are
+// the faster ones (round 5, same-box A/B in fresh processes: 0.620 / 0.628 ms ordinary, 0.597 / 0.595 ms non-temporal;
+// profiles/r05/r05b_knob_ab_C3.log): the threshold is X > 2 MB. BIGKRLS_KB_NT=0|1 overrides.
 static int kb_nontemporal(int64_t rows, int64_t p) {
   static const int env = [] { const char* e = getenv("BIGKRLS_KB_NT"); return e ? atoi(e) : -1; }();
   if (env >= 0) return env != 0;
-  return rows * p * (int64_t)sizeof(double) > (7ll << 19);    // 3.5 MB
+  return rows * p * (int64_t)sizeof(double) > (2ll << 20);    // 2 MB
 }
 
 int kernel_block(bigkrls_ctx* ctx, const double* A, int64_t u, int64_t lda, const double* B,

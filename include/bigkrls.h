@@ -36,9 +36,15 @@
  * they are launched with grids no larger than the co-resident capacity of the
  * device and every wait is bounded: when a watchdog fires (the workgroups were not
  * co-resident, e.g. another process held part of the GPU) the decomposition is
- * redone in the same call with one launch per step -- never a hang, and an error
- * (BIGKRLS_EHIP, on every rank) only from the partitioned stage 1 of
- * bigkrls_fit_dist, which cannot be replayed.
+ * redone in the same call with one launch per step -- never a hang. In
+ * bigkrls_fit_dist the watchdog of ONE rank is agreed on by all ranks and the
+ * partitioned decomposition is replayed once on every rank from a fresh copy of
+ * its column block of K (csrc/fit.hip); BIGKRLS_EHIP (on every rank) only if the
+ * replay fails too.
+ * Diagnostics: with BIGKRLS_TRACE_DIR=<dir> set, every process appends 64-bit hashes
+ * of its collectives' inputs / outputs and of the fit's intermediate results to
+ * <dir>/pid<pid>.trace (csrc/trace.hip; compared by tools/trace_diff.py). Off
+ * otherwise (one environment lookup per process).
  */
 #ifndef BIGKRLS_H
 #define BIGKRLS_H
@@ -78,10 +84,12 @@ int bigkrls_ctx_release_workspace(bigkrls_ctx* ctx);
 /* HIP-event sampling of the dominant kernels on their launch streams (used by
  * bench.py for the roofline figures; off by default). Names and their `work`:
  * "kernel_block" (flops 2*u*v*p), "band_av" (A22 V of a stage-1 panel, flops),
- * "band_update" / "band_update2" (trailing update per panel at k = 128 / the pieces
- * of the two-panel update at k = 256, flops), "panel_qr" and "bulge_chase"
- * (algorithmic bytes), "lanczos_kb" / "lanczos_cgs2" (block-Lanczos step, flops),
- * "symv" (one-stage path, bytes of the lower triangle streamed). */
+ * "band_update" / "band_update2" / "band_update4" (trailing update per panel at
+ * k = 128 / the pieces of the two-panel update at k = 256 / the four-panel update at
+ * k = 512, flops), "panel_qr" and "bulge_chase" (algorithmic bytes), "lanczos_kb" /
+ * "lanczos_cgs2" (block-Lanczos step, flops), "symv" (one-stage path, bytes of the
+ * lower triangle streamed), "solveforc_probe", "deriv_rows", "yhat_gemv" (algorithmic
+ * bytes: 8 N K per probe, 8 N^2, 8 N^2), "vcov_syrk" (N (N + 1) K flops per matrix). */
 int bigkrls_ctx_set_profile(bigkrls_ctx* ctx, int enable);
 int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms,
                             double* total_work, int64_t* launches);

@@ -4,7 +4,7 @@ single-GPU fits (no communicator, no collectives, no host round trips), the same
 hashes of its intermediate results (BIGKRLS_TRACE_DIR) and must reproduce its process's first fit bit for bit
 (tools/trace_diff.py --repeat).
 
-    python tools/oversub_single.py [--minutes M] [--procs P] [--reps K]
+    python tools/oversub_single.py [--minutes M] [--procs P] [--reps K] [--small] [--no-trace] [--arms "ENV=1|-"]
 """
 import os
 import shutil
@@ -15,6 +15,9 @@ import time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 SHAPES = [(3000, 8, None), (2500, 6, None), (300, 4, 0.001), (1200, 5, 0.01), (11700, 6, 0.001), (13500, 6, 0.001), (900, 4, 0.001),
           (17000, 10, None)]
+if "--small" in sys.argv:     # many short fits (more fits per minute): the sizes of the multi-rank cases that failed
+    SHAPES = [(3000, 8, None), (2500, 6, None), (300, 4, 0.001), (1200, 5, 0.01), (900, 4, 0.001), (600, 4, 0.001), (3000, 8, None),
+              (11700, 6, 0.001)]
 
 
 def arg(name, default):
@@ -42,6 +45,11 @@ def worker():
 
 def main():
     minutes, nprocs, reps = arg("--minutes", 10.0), arg("--procs", 24), arg("--reps", 4)
+    # --arms "A=1;B=2|C=3|-": process i runs with the environment of arm i mod len(arms) ("-" = nothing set): same load,
+    # same moment, the failures counted per arm
+    arms = arg("--arms", "-").split("|")
+    arm_fits = {a: 0 for a in arms}
+    arm_bad = {a: 0 for a in arms}
     out = os.path.join(ROOT, "gpurun_out", "oversub_single")
     os.makedirs(out, exist_ok=True)
     t_end = time.time() + 60.0 * minutes
@@ -55,22 +63,31 @@ def main():
             shutil.rmtree(tdir, ignore_errors=True)
             os.makedirs(tdir)
             env = dict(os.environ, BIGKRLS_TRACE_DIR=tdir)
-            if i % 2 == 0:
+            if "--no-trace" in sys.argv:
+                env.pop("BIGKRLS_TRACE_DIR")
+            if (i // len(arms)) % 2 == 0:
                 env.update(BIGKRLS_PQ="steps", BIGKRLS_BC="wavefront")
+            arm = arms[i % len(arms)]
+            if arm != "-":
+                for kv in arm.split(";"):
+                    k, v = kv.split("=")
+                    env[k] = v
             log = open(os.path.join(tdir, "log.txt"), "w")
             procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(n), str(p), str(trunc), str(reps)],
-                                           stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env), log, tdir))
+                                           stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, env=env), log, tdir, arm))
         load = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--steps", "4", "--warmup", "1",
                                  "--no-cpu-baseline"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
-        for p, log, tdir in procs:
+        for p, log, tdir, arm in procs:
             rc = p.wait()
             log.close()
             fits += reps
-            d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_diff.py"), tdir, "--repeat", "--quiet"],
-                               capture_output=True, text=True)
+            arm_fits[arm] += reps
+            d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_diff.py"), tdir, "--repeat", "--quiet"] if
+                               "--no-trace" not in sys.argv else [sys.executable, "-c", "pass"], capture_output=True, text=True)
             if rc != 0 or d.returncode != 0:
                 bad += 1
-                print(f"round {r}: {os.path.basename(tdir)} rc={rc} trace_diff={d.returncode}\n  " +
+                arm_bad[arm] += 1
+                print(f"round {r}: {os.path.basename(tdir)} arm [{arm}] rc={rc} trace_diff={d.returncode}\n  " +
                       "\n  ".join(open(os.path.join(tdir, "log.txt")).read().splitlines()[-3:]) + "\n" + d.stdout, flush=True)
             else:
                 shutil.rmtree(tdir, ignore_errors=True)
@@ -78,6 +95,8 @@ def main():
         print(f"round {r} done: {fits} single-GPU fits so far, {bad} bad processes, {time.time() - (t_end - 60 * minutes):.0f} s", flush=True)
         r += 1
     print(f"single-GPU fits {fits}, bad processes {bad}")
+    for a in arms:
+        print(f"arm [{a}]: {arm_fits[a]} fits, {arm_bad[a]} processes with a wrong fit")
 
 
 if __name__ == "__main__":

@@ -39,5 +39,36 @@ int main() {
     }
     printf("%9zu bytes: source read late in %d of %d runs\n", bytes, late, reps);
   }
+  // ---- a burst: many asynchronous copies from different pageable buffers queued behind one busy stream (what one level
+  //      of the divide & conquer does: ~12 uploads of n doubles / ints back to back), every source overwritten at once
+  for (size_t bytes : {(size_t)7200, (size_t)24576, (size_t)160000, (size_t)1 << 20}) {
+    const int NB = 24;
+    int wrong = 0;
+    for (int rep = 0; rep < 20; ++rep) {
+      std::vector<unsigned char*> h(NB), d(NB);
+      for (int i = 0; i < NB; ++i) {
+        h[i] = (unsigned char*)malloc(bytes);
+        CK(hipMalloc((void**)&d[i], bytes));
+        memset(h[i], 10 + i, bytes);
+      }
+      hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, st, 500000LL);     // 5 ms
+      for (int i = 0; i < NB; ++i) CK(hipMemcpyAsync(d[i], h[i], bytes, hipMemcpyHostToDevice, st));
+      for (int i = 0; i < NB; ++i) memset(h[i], 200, bytes);
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned char> back(bytes);
+      for (int i = 0; i < NB; ++i) {
+        CK(hipMemcpy(back.data(), d[i], bytes, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t k = 0; k < bytes; ++k) bad += back[k] != (unsigned char)(10 + i);
+        if (bad) {
+          ++wrong;
+          if (wrong <= 3) printf("burst of %d x %zu bytes: copy %d arrived with %zu wrong bytes (first byte %d)\n", NB, bytes, i, bad, (int)back[0]);
+        }
+        CK(hipFree(d[i]));
+        free(h[i]);
+      }
+    }
+    printf("burst of %d copies x %zu bytes behind a busy stream, 20 repetitions: %d copies arrived wrong\n", NB, bytes, wrong);
+  }
   return 0;
 }
