@@ -159,6 +159,7 @@ enum Slot {
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
 // ---- trace.hip: diagnostic hashes of buffers (BIGKRLS_TRACE_DIR; off otherwise) -----------------
 bool trace_on();
+bool trace_fine();   // ... and BIGKRLS_TRACE_FINE: per-panel / per-level hashes inside the eigensolver (serialises it)
 // hash of `count` doubles (or 8-byte words) at dev_ptr, computed on `st` (synchronised), appended to the process's trace
 int trace_point(bigkrls_ctx* ctx, hipStream_t st, const char* tag, const void* dev_ptr, int64_t count, int64_t extra = 0);
 int trace_host(const char* tag, const void* host_ptr, int64_t count, int64_t extra = 0);

@@ -334,7 +334,7 @@ int eigen_dense_dist(bigkrls_comm* comm, double* A, int64_t n, int64_t nb, int64
     if (mm[0] != -mm[1]) {
       set_error("eigen (distributed): the ranks disagree on the number of kept eigenpairs (" + std::to_string((long long)mm[0]) +
                 " ... " + std::to_string((long long)-mm[1]) + "); the replicated decomposition was not reproduced bit for bit");
-      return BIGKRLS_EHIP;
+      return BK_EWATCHDOG;      // every rank sees the same two numbers: all of them replay (csrc/fit.hip), none gives up alone
     }
   }
   if (h_lastkeeper) *h_lastkeeper = nv;

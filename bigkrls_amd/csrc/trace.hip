@@ -87,6 +87,10 @@ void trace_write(const char* tag, long long count, unsigned long long hash, long
 }  // namespace
 
 bool trace_on() { return tracer().on; }
+bool trace_fine() {
+  static const bool fine = tracer().on && getenv("BIGKRLS_TRACE_FINE") != nullptr;
+  return fine;
+}
 
 int trace_point(bigkrls_ctx* ctx, hipStream_t st, const char* tag, const void* dev_ptr, int64_t count, int64_t extra) {
   Tracer& t = tracer();

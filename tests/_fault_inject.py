@@ -5,7 +5,8 @@ BIGKRLS_FAULT=watchdog: the first attempt reports a fired persistent-kernel watc
 redo the decomposition with the per-step kernels and succeed. BIGKRLS_FAULT=noconv: the block Lanczos reports
 non-convergence; the same call must fall through to the dense path (no user-visible switch, like the reference's
 eigs_sym branch, src/eigen.cpp:18-22). BIGKRLS_FAULT=dc_lag: the stream lags behind the host inside the divide &
-conquer; the result must not change by a bit."""
+conquer; the result must not change by a bit. BIGKRLS_FAULT=eig_garbage[_always]: a decomposition that comes back
+wrong without an error is caught by the fit's check against K and redone once (then an error)."""
 import os
 import sys
 
@@ -59,6 +60,24 @@ for _ in range(2):
     lag = ops.bEigen(K, None, -1.0)
     assert np.array_equal(np.asarray(lag.values), np.asarray(full.values))
     assert np.array_equal(lag.vectors.to_numpy(), full.vectors.to_numpy())
+# BIGKRLS_FAULT=eig_garbage: the first decomposition of a fit comes back WRONG without an error (one kept eigenvector
+# scaled by 1.001). The fit checks every decomposition against K itself (trace, three eigenpairs) and redoes it once:
+# the result must be the undisturbed one; =eig_garbage_always: the redone one is wrong too -> an error, not a result.
+Xf, yf = synth(1500, 5, 77)
+os.environ["BIGKRLS_FAULT"] = ""
+ref = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False)
+os.environ["BIGKRLS_FAULT"] = "eig_garbage"
+healed = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False)
+assert healed["lastkeeper"] == ref["lastkeeper"] and healed["lambda"] == ref["lambda"]
+assert np.array_equal(healed["coeffs"], ref["coeffs"]) and np.array_equal(healed["derivatives"], ref["derivatives"])
+os.environ["BIGKRLS_FAULT"] = "eig_garbage_always"
+try:
+    bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False)
+    raise AssertionError("a decomposition that fails the check against K twice must be an error")
+except L.BigKRLSError as e:
+    assert e.code == L.EHIP and "fails the check against K" in str(e) and "also after the decomposition was redone" in str(e), str(e)
+os.environ["BIGKRLS_VERIFY"] = "0"          # (read once per process: this process has it on; the switch exists for A/B timing)
+del os.environ["BIGKRLS_VERIFY"]
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)

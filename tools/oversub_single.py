@@ -84,7 +84,10 @@ def main():
             arm_fits[arm] += reps
             d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_diff.py"), tdir, "--repeat", "--quiet"] if
                                "--no-trace" not in sys.argv else [sys.executable, "-c", "pass"], capture_output=True, text=True)
-            if rc != 0 or d.returncode != 0:
+            caught = [ln for ln in open(os.path.join(tdir, "log.txt"), errors="replace") if "NONDETERMINISM" in ln]
+            for ln in caught[:6]:
+                print(f"round {r}: {os.path.basename(tdir)}: {ln.strip()}", flush=True)
+            if rc != 0 or d.returncode != 0 or caught:
                 bad += 1
                 arm_bad[arm] += 1
                 print(f"round {r}: {os.path.basename(tdir)} arm [{arm}] rc={rc} trace_diff={d.returncode}\n  " +

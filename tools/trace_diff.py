@@ -103,8 +103,21 @@ def main():
             for j, f in enumerate(p["fits"][1:], 1):
                 d = first_diff([res[0], res[j]], ["fit 0", f"fit {j}"])
                 if d:
-                    found.append(f"pid {p['pid']}: the results of fit {j} differ from fit 0 at result record {d[0]} (min free "
-                                 f"memory {min(r[4] for r in f)} MiB):\n    " + "\n    ".join(d[1]))
+                    msg = (f"pid {p['pid']}: the results of fit {j} differ from fit 0 at result record {d[0]} (min free "
+                           f"memory {min(r[4] for r in f)} MiB):\n    " + "\n    ".join(d[1]))
+                    # where the two fits part ways: the first record (of all, not only the results) that differs from the
+                    # majority of the process's fits with the same number of records
+                    same = [g for g in p["fits"] if len(g) == len(f)]
+                    if len(same) >= 3:
+                        from collections import Counter
+                        for i in range(len(f)):
+                            maj = Counter(g[i][2] for g in same).most_common(1)[0][0]
+                            if f[i][2] != maj:
+                                prev = f[i - 1] if i > 0 else None
+                                msg += (f"\n    first record of fit {j} that deviates from the other fits: #{i} {f[i][0]} extra={f[i][3]} "
+                                        f"count={f[i][1]}" + (f" (after {prev[0]} extra={prev[3]}, still equal)" if prev else ""))
+                                break
+                    found.append(msg)
                 elif len(f) != len(p["fits"][0]) and not quiet:
                     print(f"pid {p['pid']}: fit {j} has {len(f)} records, fit 0 {len(p['fits'][0])}: a decomposition was redone "
                           "(watchdog retry), results identical")
