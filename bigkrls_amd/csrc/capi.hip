@@ -40,8 +40,31 @@ int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out) {
       return BIGKRLS_ENOMEM;
     }
     ctx->ws_bytes[slot] = want;
+    // BIGKRLS_POISON=1 (diagnostics): a fresh slab starts as all-ones bytes (NaN as a double, -1 as an index), so that
+    // anything read before it is written shows up at once instead of depending on what the memory held before
+    if (ws_poison()) {   // (on the context's stream: hipMemset runs on the NULL stream, asynchronously to the host)
+      BK_HIP(hipMemsetAsync(ctx->ws[slot], 0xFF, (size_t)want, ctx->stream));
+      BK_HIP(hipStreamSynchronize(ctx->stream));
+    }
   }
   *out = ctx->ws[slot];
+  return BIGKRLS_OK;
+}
+
+bool ws_poison() {
+  static const bool on = getenv("BIGKRLS_POISON") != nullptr;
+  return on;
+}
+
+// BIGKRLS_POISON=1: every slab the context holds back to all-ones bytes (called at the start of a fit: what the
+// previous call left behind must not be read by this one)
+int ws_poison_all(bigkrls_ctx* ctx) {
+  if (!ws_poison()) return BIGKRLS_OK;
+  BK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->side_stream && !ctx->side_is_main) BK_HIP(hipStreamSynchronize(ctx->side_stream));
+  for (int i = 0; i < bigkrls_ctx::kSlots; ++i)
+    if (ctx->ws[i] && i != SLOT_COMM_SMALL) BK_HIP(hipMemsetAsync(ctx->ws[i], 0xFF, (size_t)ctx->ws_bytes[i], ctx->stream));
+  BK_HIP(hipStreamSynchronize(ctx->stream));
   return BIGKRLS_OK;
 }
 

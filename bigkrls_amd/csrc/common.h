@@ -157,6 +157,8 @@ enum Slot {
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
+bool ws_poison();                      // BIGKRLS_POISON (diagnostics): fresh workspace starts as all-ones bytes ...
+int ws_poison_all(bigkrls_ctx* ctx);   // ... and every slab is reset to them at the start of a fit
 // ---- trace.hip: diagnostic hashes of buffers (BIGKRLS_TRACE_DIR; off otherwise) -----------------
 bool trace_on();
 bool trace_fine();   // ... and BIGKRLS_TRACE_FINE: per-panel / per-level hashes inside the eigensolver (serialises it)

@@ -1397,13 +1397,11 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     // eigenvector update
     int maxKneed = 0;
     for (int q = 0; q < nm; ++q) maxKneed = std::max(maxKneed, descs[q].Kneed);
-    // Descriptors of this level's batched products. Declared HERE, not inside the branch that fills them: the vector is
-    // the source of an asynchronous host -> device copy, and the runtime reads a pageable source of more than a few KB
-    // when the copy EXECUTES on the stream (it pins the user pages; tools/pageable_h2d_probe.hip), not when
-    // hipMemcpyAsync returns -- so it has to stay alive and untouched until the synchronisation at the end of the level.
-    // (Round 5: it used to be a local of that branch, freed before the synchronisation. With the stream running late --
-    // many processes on one GPU -- the copy then read freed heap memory: garbage descriptors, a wrong eigenvector block
-    // at one level, wrong eigenvalues above it, no error. DESIGN.md section 7.)
+    // Descriptors of this level's batched products: a source of an asynchronous host -> device copy, declared at the
+    // level's scope so that it lives until the synchronisation at the end of the level. (It used to be a local of the
+    // branch that fills it, destroyed before that synchronisation. On this runtime that was harmless -- hipMemcpyAsync
+    // takes its copy of a pageable source before it returns, at every size, also in bursts and under load:
+    // tools/pageable_h2d_probe.hip, BIGKRLS_FAULT=dc_gd_clobber -- but nothing in the API promises it.)
     std::vector<GemmDesc> gd;
     if (maxKneed > 0) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
@@ -1494,8 +1492,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
 #ifdef BK_FAULT_INJECT
       // BIGKRLS_FAULT=dc_lag (test build): the stream runs 2 ms behind the host, as it does with many processes on one
       // GPU -- the copy below executes long after hipMemcpyAsync has returned. =dc_gd_clobber additionally overwrites
-      // the descriptors right after the launch (what freeing them early amounted to): the level then goes WRONG, which
-      // is how tools/dc_async_source_probe.py shows that the source is read when the copy executes.
+      // the descriptors right after the launch (what freeing them early amounted to): tools/dc_async_source_probe.py
+      // uses it to see WHEN the runtime reads a pageable source (result: before hipMemcpyAsync returns).
       const char* dc_fault = getenv("BIGKRLS_FAULT");
       const bool dc_lag = dc_fault && (std::string(dc_fault) == "dc_lag" || std::string(dc_fault) == "dc_gd_clobber");
       if (dc_lag) hipLaunchKernelGGL(dc_fault_spin, dim3(1), dim3(64), 0, st, 200000LL);

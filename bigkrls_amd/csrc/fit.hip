@@ -260,6 +260,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   double* dK = out->d_K ? out->d_K : (double*)pk;
 
   if (trace_on()) BK_TRY(trace_host("L:fit_begin", nullptr, 0, n));
+  BK_TRY(ws_poison_all(ctx));
   PhaseTimer timer(ctx);
   timer.mark();
   // ---- standardise (R/bigKRLS.R:248-254) straight into the pinned staging buffer, upload ----------

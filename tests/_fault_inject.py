@@ -51,8 +51,9 @@ res, orth = quality(K, third.vectors, third.values)
 assert res < 1e-11 and orth < 1e-11, (res, orth)
 # BIGKRLS_FAULT=dc_lag: the stream runs 2 ms behind the host inside the divide & conquer (a spin kernel ahead of each
 # level's descriptor upload) while the host churns its heap: every host vector that is the source of an asynchronous
-# copy must stay alive and untouched until the level is synchronised. (The regression of round 5: one of them was
-# freed early and a late copy read garbage -- wrong eigenvalues, no error.) All eigenvectors: the explicit merges.
+# copy must stay alive and untouched until the level is synchronised (one of them used to be freed early: harmless on
+# this runtime, which copies a pageable source before hipMemcpyAsync returns, but not promised). All eigenvectors:
+# the explicit merges.
 os.environ["BIGKRLS_FAULT"] = ""
 full = ops.bEigen(K, None, -1.0)
 os.environ["BIGKRLS_FAULT"] = "dc_lag"

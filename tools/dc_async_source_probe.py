@@ -1,8 +1,8 @@
-"""Shows on the device what the divide & conquer's round-5 bug relied on NOT happening: with the stream running late,
-a pageable host vector that is the source of hipMemcpyAsync is read when the copy EXECUTES. Test build of the library,
-BIGKRLS_FAULT=dc_gd_clobber: a spin kernel keeps the stream 2 ms behind, the descriptor vector of each level's batched
-product is zeroed right after the launch (what freeing it early amounted to once the heap block was reused). If the
-runtime had taken its copy when hipMemcpyAsync returned, the result would be unchanged.
+"""When does the runtime read a pageable host vector that is the source of hipMemcpyAsync -- when the call returns, or
+when the copy executes? Test build of the library, BIGKRLS_FAULT=dc_gd_clobber: a spin kernel keeps the stream 2 ms
+behind, and the descriptor vector of each level's batched product in the divide & conquer is zeroed right after the
+launch. Result on this runtime (profiles/r05/r05b_dc_async_source_probe.log): the decomposition does not change by a
+bit -- the copy was taken at the call, as tools/pageable_h2d_probe.hip shows at every size.
     python tools/dc_async_source_probe.py"""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")

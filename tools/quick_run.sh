@@ -1,5 +1,5 @@
 # quick GPU check: tests + smoke + C2/C3 bench lines   (EVID=tag)
-O=gpurun_out/${EVID:-r04a}; mkdir -p $O
+O=gpurun_out/${EVID:-r05a}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q --durations=8 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
