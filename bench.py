@@ -17,8 +17,10 @@ partitioned over the ranks (strong scaling): see bigkrls_amd/dist.py.
 the most time on the critical path (dense path: the stage-1 band update / A22 V GEMMs, bulge
 chasing, or the one-stage symv; Neig << N: the K B_j product of the block Lanczos) --
 measured live with HIP events on the launch stream; the panel QR, which runs concurrently
-on the look-ahead stream, is listed in `other_kernels`; `kernel_gemm` reports the
-Gaussian-kernel GEMM the metric names.
+on the look-ahead stream, is listed in `other_kernels`; `roofline.kernel_gemm` reports the
+Gaussian-kernel GEMM the metric names (time, TFLOP/s, HBM-write GB/s). The line is compact
+(< 5 KB: the driver keeps the tail of stdout); `--long-json` adds every entry's definition
+(DESIGN.md section 5 has them).
 `cpu_baseline` times the oracle's literal restatement of the reference on the host cores at
 the bench size (oracle/cpu_baseline.py, a child process started before the GPU is touched
 and released after the GPU timing; rank 0, N=1 only), bounded by --cpu-budget-s.

@@ -2711,8 +2711,10 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const char* fault = getenv("BIGKRLS_FAULT");
     const bool once = fault && std::string(fault) == "eig_garbage", always = fault && std::string(fault) == "eig_garbage_always";
     if (!once && !always) garbage_calls = 0;
-    if ((always || (once && garbage_calls++ == 0)) && nv > 0 && n_vecs_max > 0 && part_count == 1)
-      BK_TRY(scale(ctx, N, 1.001, vecs + (int64_t)(nv / 2) * ldv));
+    // (a column the fit's check samples: the middle kept one; in a multi-GPU fit the last one, owned by the last rank)
+    const int gc = part_count == 1 ? nv / 2 : nv - 1;
+    if ((always || (once && garbage_calls++ == 0)) && nv > 0 && n_vecs_max > 0 && part_index == part_count - 1)
+      BK_TRY(scale(ctx, N, 1.001, vecs + (int64_t)gc * ldv));
   }
 #endif
   if (trace_on() && nv > 0 && n_vecs_max > 0) {

@@ -428,10 +428,26 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
       if (std::isnan(vals[i])) return true;
     return false;
   };
+  // (every decision below is taken by ALL ranks together: after a fault one rank's copy of the replicated eigenvalues
+  //  may hold NaNs or no kept pair while its peers' copies are fine -- a rank that left the loop on its own would
+  //  leave the others waiting in the next collective)
+  bool nan_agreed = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
     BK_TRY(run_eigen());
-    if (has_nan()) break;                    // (the reference's own message below; every rank holds the same values)
-    const int rc_v = agreed(verify());
+    int rc_v;
+    if (has_nan() || lastkeeper <= 0) {
+      set_error(has_nan() ? "fit: NaN among the eigenvalues" : "fit: no eigenpair passes the eigtrunc threshold");
+      rc_v = agreed(BK_EWATCHDOG);
+    } else {
+      rc_v = agreed(verify());
+    }
+    {
+      // NaNs on every attempt are the input's doing (the reference's message below), not a fault to retry for ever
+      double nn = has_nan() ? -1.0 : 0.0;
+      if (comm) BK_TRY(comm_all_reduce_host(comm, &nn, 1, COMM_MIN));
+      nan_agreed = nn < 0.0;
+    }
+    if (attempt == 1 && nan_agreed) break;
     if (rc_v == BIGKRLS_OK) break;
     if (rc_v != BK_EWATCHDOG) return rc_v;
     if (attempt == 1) {
@@ -441,10 +457,9 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     if (getenv("BIGKRLS_VERBOSE") || getenv("BIGKRLS_REPORT_REDO"))
       fprintf(stderr, "[bigkrls] %s; redoing the decomposition\n", bigkrls_last_error());
   }
-  for (int64_t i = 0; i < neig; ++i)
-    if (std::isnan(vals[i]))
-      return fail("Missing eigenvalues prevent bigKRLS from obtaining the regularization parameter lambda.\n\t"
-                  "Check for repeated observations (or other perfect linear combinations in X).");
+  if (nan_agreed)
+    return fail("Missing eigenvalues prevent bigKRLS from obtaining the regularization parameter lambda.\n\t"
+                "Check for repeated observations (or other perfect linear combinations in X).");
   BK_REQUIRE(lastkeeper > 0, "fit: no eigenpair passes the eigtrunc threshold");
   const int64_t k = lastkeeper;
   if (trace_on()) {   // diagnostics (csrc/trace.hip): what every rank holds after the decomposition

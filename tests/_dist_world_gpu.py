@@ -75,6 +75,16 @@ def worker():
         if rank == watchdog_rank:
             os.environ["BIGKRLS_FAULT"] = "watchdog"
         os.environ["BIGKRLS_VERBOSE"] = "1"
+    garbage_rank = int(sys.argv[sys.argv.index("--garbage-rank") + 1]) if "--garbage-rank" in sys.argv else None
+    if garbage_rank is not None:
+        # the test build once more: ONE rank's slice of the eigenvectors comes back wrong WITHOUT an error (its last kept
+        # column scaled by 1.001). Every rank checks the decomposition against its own rows of K, the failure is agreed
+        # on, all ranks redo the decomposition, and the fit ends with the right answer
+        import bigkrls_amd._lib as L
+        L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "libbigkrls_hip_fault.so")
+        if rank == garbage_rank:
+            os.environ["BIGKRLS_FAULT"] = "eig_garbage"
+        os.environ["BIGKRLS_REPORT_REDO"] = "1"
     if fault_rank is not None:
         # the test build of the library (fault-injection hooks compiled in); the fault itself only in ONE rank's process
         import bigkrls_amd._lib as L

@@ -24,6 +24,9 @@ WORLD_CASES = {
     "dense_world2_rank_failure": ["600", "4", "2", "--eigtrunc", "0.001", "--fault-rank", "1"],                # n <= 256: K gathered, Q by all-reduce
     # ONE rank's persistent-kernel watchdog fires (test build): agreed on by all ranks, decomposition replayed everywhere
     "dense_world2_watchdog_replay": ["900", "4", "2", "--eigtrunc", "0.001", "--watchdog-rank", "1"],
+    # ONE rank's eigenvector slice comes back wrong without an error (test build): the fit's check against K catches it on
+    # every rank's own rows, the failure is agreed on and the decomposition redone everywhere
+    "dense_world2_garbage_redo": ["900", "4", "2", "--eigtrunc", "0.001", "--garbage-rank", "1"],
     # The product's own communicator path (unique id -> bigkrls_comm_create -> the dlopen'd function table, collectives
     # asynchronous on the context's stream) over tests/mock_rccl, with the library's DEFAULT kernels ("--default-knobs":
     # the persistent panel factorisation / bulge chasing beside the collectives; a watchdog that fires because the rank

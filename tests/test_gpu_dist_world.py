@@ -24,6 +24,9 @@ def test_world_n_hip_backend_matches_single_fit(world_runs, name):
     assert rc == 0, text[-4000:]
     ok_lines = [ln for ln in text.splitlines() if ln.startswith("rank ") and ln.rstrip().endswith(" OK")]
     assert len(ok_lines) == world, text[-4000:]
+    if name.endswith("garbage_redo"):
+        # every rank must have redone the decomposition (the wrong slice was one rank's; the decision is agreed)
+        assert text.count("redoing the decomposition") == world, text[-4000:]
     if name.endswith("watchdog_replay"):
         # the fault fired in ONE rank; every rank must have replayed (the decision is agreed, not local)
         assert text.count("replaying the distributed decomposition") == world, text[-4000:]

@@ -29,7 +29,9 @@ def worker():
     import bigkrls_amd as bk
     from bigkrls_amd.synth import synth
     n, p, trunc, reps = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
-    ctx = bk.Context(0)
+    # (OVERSUB_OWN_STREAM=1: a stream of the context's own instead of the process's default (NULL) stream, on which
+    #  every other Python-driven fit of this repository runs)
+    ctx = bk.Context(0, own_stream=bool(os.environ.get("OVERSUB_OWN_STREAM")))
     X, y = synth(n, p, 103)
     kw = {} if trunc == "None" else dict(eigtrunc=float(trunc))
     if n == 17000:
