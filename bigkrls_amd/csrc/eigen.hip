@@ -2132,7 +2132,8 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
                          (const double*)dAall, (const double*)dBall, steps, b, dT);
       BK_CHECK_LAUNCH();
       int64_t nvY = 0;
-      BK_TRY(eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1, EIG_FULL));
+      // (replicated, but after a fault one rank's copy may fail where its peers' do not: agreed, so nobody leaves alone)
+      BK_TRY(kry_agree_status(kop, eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1, EIG_FULL)));
       // theta (m values) and the last b rows of Y come down through the context's pinned buffer
       double* hp = nullptr;
       BK_TRY(pinned_get(ctx, m + (int64_t)b * k, &hp));

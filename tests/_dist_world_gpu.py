@@ -24,28 +24,71 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
+PORT_TAKEN = 97      # exit code of a rank whose rendezvous port was taken between the launcher's probe and its own bind
+
+
 def launcher():
+    import socket
+    import time
     args = [a for a in sys.argv[1:]]
     pos = [a for a in args if a.isdigit()][:3]
     world = int(pos[2]) if len(pos) > 2 else 2
-    # a port of its own (a scheme by PID collides when thread IDs -- the same number space -- push the launchers' PIDs
-    # a multiple of the table size apart)
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = str(sk.getsockname()[1])
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, BIGKRLS_DIST_WORKER="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args, env=env))
-    rc = 0
-    for p in procs:
-        rc |= p.wait()
-    sys.exit(rc)
+    for attempt in range(4):
+        # a port of its own (a scheme by PID collides when thread IDs -- the same number space -- push the launchers' PIDs
+        # a multiple of the table size apart). Probing for a free port and binding it later is a race with every other
+        # launcher and with gloo's own ephemeral connections: when rank 0 finds the port taken (before any library code
+        # has run) the rendezvous -- only the rendezvous -- is started again on another port.
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=port, BIGKRLS_DIST_WORKER="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args, env=env))
+        # a rank that dies leaves its peers inside a collective (or inside the rendezvous) for ever: once one has failed,
+        # the others get a minute and are then ended (these exact PIDs) -- a failure, never a hang
+        codes = [None] * world
+        t_fail = None
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if t_fail is None and any(c not in (None, 0) for c in codes):
+                t_fail = time.time()
+            if t_fail is not None and (PORT_TAKEN in codes or time.time() - t_fail > 60.0):
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.kill()
+                        codes[i] = p.wait() or 1
+                break
+            time.sleep(0.05)
+        if PORT_TAKEN in codes and attempt < 3:
+            print(f"[launcher] rendezvous port {port} was taken before rank 0 could bind it; starting the ranks again", flush=True)
+            continue
+        rc = 0
+        for c in codes:
+            rc |= (c if c is not None else 1)
+        sys.exit(1 if rc else 0)
 
 
 def worker():
+    selftest = os.environ.get("BIGKRLS_LAUNCHER_SELFTEST")
+    if selftest:
+        # CPU self-test of the launcher (tests/test_world_supervisor_cpu.py): "port": rank 0 finds its port taken once;
+        # "dead": rank 1 dies and rank 0 would wait for it for ever
+        import time
+        rank = int(os.environ["RANK"])
+        marker = os.environ["BIGKRLS_LAUNCHER_MARKER"]
+        if selftest == "port":
+            if rank == 0 and not os.path.exists(marker):
+                open(marker, "w").close()
+                sys.exit(PORT_TAKEN)
+            time.sleep(0.3 if os.path.exists(marker) else 30.0)
+            sys.exit(0)
+        if rank == 1:
+            sys.exit(3)
+        time.sleep(600.0)
     sys.path.insert(0, ROOT)
     import time
     import numpy as np
@@ -94,7 +137,12 @@ def worker():
     mock = "--rccl-mock" in sys.argv
     if mock:
         os.environ["BIGKRLS_RCCL_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mock_rccl", "libmock_rccl.so")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    except Exception as e:              # (torch.distributed.DistNetworkError: EADDRINUSE on rank 0)
+        if "EADDRINUSE" in str(e) or "address already in use" in str(e):
+            sys.exit(PORT_TAKEN)
+        raise
     ctx = bk.Context(0)
     if mock:
         comm = bkdist.get_comm(ctx, "rccl")               # bigkrls_comm_unique_id / bigkrls_comm_create: the product's path
