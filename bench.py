@@ -683,8 +683,8 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "next panel's factorisation (stage 1 while the trailing matrix has >= 12800 rows)",
                        "achieved = 512 m^2 algorithmic flops per launch (lower triangle) / HIP-event duration on the launch "
                        "stream, every second group bracketed (total_ms_per_fit = 2 x the sampled time); traffic = algorithmic "
-                       "HBM bytes (12 bytes per 512 flops) x the whole-triangle k = 512 ratio of profiles/r03/r03b_syrk_traffic_pmc.json (1.145)",
-                       traffic=(lambda flops: round(12.0 * flops / 512.0 * 1.145, 0)),
+                       "HBM bytes (12 bytes per 512 flops) x the whole-triangle k = 512 ratio of profiles/r05/r05u_syrk_traffic_pmc.json (1.146; 1.145 in round 3)",
+                       traffic=(lambda flops: round(12.0 * flops / 512.0 * 1.146, 0)),
                        stride=2),
             mfma_entry("band_av", "gemm_kernel<N,N,64>: Y = A22 V (stage 1), one launch per panel",
                        "achieved = 2 m^2 b flops per launch (b = 64) / HIP-event duration; traffic = algorithmic HBM bytes of "
