@@ -118,7 +118,7 @@ int resident_capacity(bigkrls_ctx* ctx, const void* kernel, int* cap, int thread
 }
 
 int side_stream_get(bigkrls_ctx* ctx) {
-  if (!ctx->side_stream) {
+  if (!ctx->side_stream && !ctx->side_is_main) {   // (side_is_main: the main stream may be the NULL stream, i.e. a null handle)
     // BIGKRLS_NO_SIDE=1 (diagnostics): no second stream -- the "look-ahead" work is queued on the main stream, every
     // fork / join becomes a no-op. Slower; separates cross-stream ordering from everything else when hunting a
     // nondeterminism (tools/oversub_single.py --arms).
