@@ -62,7 +62,8 @@ for _ in range(2):
     assert np.array_equal(np.asarray(lag.values), np.asarray(full.values))
     assert np.array_equal(lag.vectors.to_numpy(), full.vectors.to_numpy())
 # BIGKRLS_FAULT=eig_garbage: the first decomposition of a fit comes back WRONG without an error (one kept eigenvector
-# scaled by 1.001). The fit checks every decomposition against K itself (trace, three eigenpairs) and redoes it once:
+# scaled by 1.001). The fit checks every decomposition against K itself (trace; two +-1 combinations of ALL kept pairs)
+# and redoes it once:
 # the result must be the undisturbed one; =eig_garbage_always: the redone one is wrong too -> an error, not a result.
 Xf, yf = synth(1500, 5, 77)
 os.environ["BIGKRLS_FAULT"] = ""
@@ -77,8 +78,6 @@ try:
     raise AssertionError("a decomposition that fails the check against K twice must be an error")
 except L.BigKRLSError as e:
     assert e.code == L.EHIP and "the check against K" in str(e) and "also after the decomposition was redone" in str(e), str(e)
-os.environ["BIGKRLS_VERIFY"] = "0"          # (read once per process: this process has it on; the switch exists for A/B timing)
-del os.environ["BIGKRLS_VERIFY"]
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)
