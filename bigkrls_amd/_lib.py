@@ -69,6 +69,7 @@ SIGNATURES = {
     "bigkrls_ctx_release_workspace": [vp],
     "bigkrls_ctx_set_profile": [vp, C.c_int],
     "bigkrls_ctx_get_profile": [vp, C.c_char_p, pf64, pf64, pi64],
+    "bigkrls_ctx_get_counters": [vp, pi64],
     "bigkrls_dev_alloc": [vp, i64, C.POINTER(vp)],
     "bigkrls_dev_free": [vp, vp],
     "bigkrls_h2d": [vp, vp, vp, i64],

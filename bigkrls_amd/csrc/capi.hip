@@ -355,6 +355,15 @@ int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms
   return BIGKRLS_OK;
 }
 
+int bigkrls_ctx_get_counters(bigkrls_ctx* ctx, int64_t out[3]) {
+  BK_TRY(check_ctx(ctx));
+  BK_REQUIRE(out, "get_counters: null output");
+  out[0] = ctx->n_redone;
+  out[1] = ctx->n_replayed;
+  out[2] = ctx->n_replica_diff;
+  return BIGKRLS_OK;
+}
+
 int64_t bigkrls_ctx_workspace_bytes(bigkrls_ctx* ctx) {
   if (!ctx) return 0;
   int64_t s = 0;

@@ -74,6 +74,14 @@ struct bigkrls_ctx {
   struct ProfEntry { std::string name; std::vector<ProfSample> pending; double ms = 0, work = 0; int64_t launches = 0; };
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per sample costs more than the sample)
+  // recovery paths taken since the context was created (bigkrls_ctx_get_counters): decompositions redone because the
+  // fit's check against K failed / replayed with per-step launches after a watchdog (or a disagreement between ranks) /
+  // replicated eigenvalues of this rank that were not rank 0's bit for bit (multi-GPU fits)
+  int64_t n_redone = 0, n_replayed = 0, n_replica_diff = 0;
+  // set by the eigensolver beside an error code when what failed can only be a fault of the run on a finite symmetric
+  // input (a block recurrence that does not hold against K, non-finite entries after the tridiagonalisation); read and
+  // cleared by the fit, which validated its input and redoes such a decomposition once (csrc/fit.hip)
+  bool corrupt_run = false;
 };
 
 // One rank of a multi-GPU job (one process per GPU): the context it computes on and the collectives that connect

@@ -86,7 +86,10 @@ int cb_fail(const char* what, int rc) {
 
 }  // namespace
 
-// BIGKRLS_TRACE_DIR (diagnostics, csrc/trace.hip): hash of what a collective is given and of what it delivers
+// BIGKRLS_TRACE_DIR (diagnostics, csrc/trace.hip): hash of what a collective is given and of what it delivers.
+// Best effort: a trace record that cannot be written (an allocation or launch that fails under the very memory pressure
+// the tool is used under) must not keep this rank out of a collective its peers are already waiting in -- the status of
+// the record taken BEFORE a collective is only reported after the collective has been issued.
 static int comm_trace(bigkrls_comm* comm, const char* tag, const double* p, int64_t count, int64_t extra) {
   if (!trace_on() || !comm->ctx) return BIGKRLS_OK;
   return trace_point(comm->ctx, comm->ctx->stream, tag, p, count, extra);
@@ -94,42 +97,48 @@ static int comm_trace(bigkrls_comm* comm, const char* tag, const double* p, int6
 
 int comm_all_reduce(bigkrls_comm* comm, double* dbuf, int64_t count, int op) {
   if (!comm || count <= 0) return BIGKRLS_OK;
-  BK_TRY(comm_trace(comm, "L:ar_in", dbuf, count, op));
+  const int rc_trace = comm_trace(comm, "L:ar_in", dbuf, count, op);
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.all_reduce(comm->cb.user, dbuf, count, op);
     if (rc) return cb_fail("all_reduce", rc);
-    return comm_trace(comm, "C:ar_out", dbuf, count, op);
+    const int rc_out = comm_trace(comm, "C:ar_out", dbuf, count, op);
+    return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
   }
   BK_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclFloat64, op == COMM_MIN ? ncclMin : ncclSum,
                            (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return comm_trace(comm, "C:ar_out", dbuf, count, op);
+  const int rc_out = comm_trace(comm, "C:ar_out", dbuf, count, op);
+  return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
 }
 
 int comm_all_gather(bigkrls_comm* comm, const double* dsend, double* drecv, int64_t count) {
   if (!comm || count <= 0) return BIGKRLS_OK;
-  BK_TRY(comm_trace(comm, "L:ag_in", dsend, count, 0));
+  const int rc_trace = comm_trace(comm, "L:ag_in", dsend, count, 0);
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.all_gather(comm->cb.user, dsend, drecv, count);
     if (rc) return cb_fail("all_gather", rc);
-    return comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
+    const int rc_out = comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
+    return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
   }
   BK_NCCL(rccl().AllGather(dsend, drecv, (size_t)count, ncclFloat64, (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
+  const int rc_out = comm_trace(comm, "C:ag_out", drecv, count * comm->nranks, 0);
+  return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
 }
 
 int comm_broadcast(bigkrls_comm* comm, double* dbuf, int64_t count, int root) {
   if (!comm || count <= 0) return BIGKRLS_OK;
-  BK_TRY(comm_trace(comm, comm->rank == root ? "L:bc_in_root" : "L:bc_in", dbuf, count, root));
+  const int rc_trace = comm_trace(comm, comm->rank == root ? "L:bc_in_root" : "L:bc_in", dbuf, count, root);
   if (comm->use_cb) {
     if (comm->ctx) BK_HIP(hipStreamSynchronize(comm->ctx->stream));
     const int rc = comm->cb.broadcast(comm->cb.user, dbuf, count, root);
     if (rc) return cb_fail("broadcast", rc);
-    return comm_trace(comm, "C:bc_out", dbuf, count, root);
+    const int rc_out = comm_trace(comm, "C:bc_out", dbuf, count, root);
+    return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
   }
   BK_NCCL(rccl().Broadcast(dbuf, dbuf, (size_t)count, ncclFloat64, root, (ncclComm_t)comm->nccl, comm->ctx->stream));
-  return comm_trace(comm, "C:bc_out", dbuf, count, root);
+  const int rc_out = comm_trace(comm, "C:bc_out", dbuf, count, root);
+  return rc_trace != BIGKRLS_OK ? rc_trace : rc_out;
 }
 
 // the device word(s) and the pinned scratch the status agreement goes through: allocated when the communicator is

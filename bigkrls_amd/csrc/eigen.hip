@@ -918,6 +918,8 @@ __global__ void dc_fault_spin(long long ticks) {
   const unsigned long long t0 = wall_clock64();
   while ((long long)(wall_clock64() - t0) < ticks) {}
 }
+// test build only: one eigenvalue moved to the next representable double (a last-bit deviation of ONE rank's replica)
+__global__ void fault_nudge_ulp(double* v) { *v = nextafter(*v, 2.0 * *v + 1.0); }
 #endif
 __global__ void dc_iota(int* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2264,6 +2266,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
         snprintf(buf, sizeof buf, "eigen (Krylov): the Ritz pairs fail the check against K itself (residual %.3e, theta_1 %.3e): "
                                   "the block recurrence was corrupted", -ag[0], ag[1]);
         set_error(buf);
+        ctx->corrupt_run = true;
         return BIGKRLS_ENOCONV;
       }
     }
@@ -2305,6 +2308,15 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     if (pc0 > 0) BK_HIP(hipMemsetAsync(vecs, 0, (size_t)pc0 * ldv * sizeof(double), st));
     if (pc1 < nv) BK_HIP(hipMemsetAsync(vecs + pc1 * ldv, 0, (size_t)(nv - pc1) * ldv * sizeof(double), st));
   }
+#ifdef BK_FAULT_INJECT
+  {
+    const char* fault = getenv("BIGKRLS_FAULT");   // BIGKRLS_FAULT=vals_ulp: see the dense path
+    if (fault && std::string(fault) == "vals_ulp" && nv > 1) {
+      fault_nudge_ulp<<<1, 1, 0, st>>>(vals + nv / 2);
+      BK_HIP(hipGetLastError());
+    }
+  }
+#endif
   BK_HIP(hipStreamSynchronize(st));
   return BIGKRLS_OK;
 }
@@ -2324,6 +2336,7 @@ static int eigen_retry_without_resident(bigkrls_ctx* ctx, const double* A, int64
   }
   if (getenv("BIGKRLS_VERBOSE"))
     fprintf(stderr, "[bigkrls] eigen: persistent-kernel watchdog fired; retrying with per-step launches\n");
+  ctx->n_replayed++;
   ctx->no_resident = true;
   const int rc = eigen(ctx, A, n64, lda, n_vals, vals, n_vecs_max, keep_thresh, vecs, ldv, h_n_vecs, part_index,
                        part_count, EIG_FULL);
@@ -2641,6 +2654,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   for (int i = 0; i < n; ++i)
     if (!std::isfinite(hd[i]) || (i < n - 1 && !std::isfinite(he[i]))) {
       set_error("eigen: non-finite entries after tridiagonalisation (NaN/Inf in the input?)");
+      ctx->corrupt_run = true;
       return BIGKRLS_EINVAL;
     }
   if (trace_on()) {
@@ -2716,6 +2730,13 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int gc = part_count == 1 ? nv / 2 : nv - 1;
     if ((always || (once && garbage_calls++ == 0)) && nv > 0 && n_vecs_max > 0 && part_index == part_count - 1)
       BK_TRY(scale(ctx, N, 1.001, vecs + (int64_t)gc * ldv));
+    // BIGKRLS_FAULT=vals_ulp (set in ONE rank's process): this rank's copy of the replicated eigenvalues differs from its
+    // peers' in the last bit of one kept value -- a valid decomposition the fit's check against K lets through; the
+    // multi-GPU fit must still run its lambda search on identical values everywhere (csrc/fit.hip: rank 0's are broadcast)
+    if (fault && std::string(fault) == "vals_ulp" && nv > 1 && keep_thresh >= 0.0) {   // (not the inner solves of the Lanczos)
+      fault_nudge_ulp<<<1, 1, 0, st>>>(vals + nv / 2);
+      BK_HIP(hipGetLastError());
+    }
   }
 #endif
   if (trace_on() && nv > 0 && n_vecs_max > 0) {

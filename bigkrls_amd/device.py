@@ -113,6 +113,14 @@ class Context:
                   C.byref(n))
         return float(ms.value), float(work.value), int(n.value)
 
+    def counters(self) -> dict:
+        """How often this context took a recovery path since it was created (all 0 in a healthy session):
+        decompositions redone after the fit's check against K failed, decompositions replayed with per-step
+        launches (watchdog / ranks that disagreed), multi-GPU fits whose replicated eigenvalues differed from rank 0's."""
+        out = (C.c_int64 * 3)()
+        _lib.call("bigkrls_ctx_get_counters", self.handle, out)
+        return {"redone": int(out[0]), "replayed": int(out[1]), "replica_diff": int(out[2])}
+
     # ---- allocation ---------------------------------------------------------
     def on_stream(self):
         """`with ctx.on_stream():` -- torch work inside is issued on the context's stream."""

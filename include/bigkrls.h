@@ -94,6 +94,15 @@ int bigkrls_ctx_set_profile(bigkrls_ctx* ctx, int enable);
 int bigkrls_ctx_get_profile(bigkrls_ctx* ctx, const char* name, double* total_ms,
                             double* total_work, int64_t* launches);
 
+/* How often this context took one of its recovery paths since it was created
+ * (a GPU test session asserts all three are 0 outside its fault-injection cases):
+ * out[0] decompositions redone because the fit's check against K failed,
+ * out[1] decompositions replayed with launch-per-step kernels (a persistent kernel's
+ *        watchdog, or ranks that kept different numbers of eigenpairs),
+ * out[2] multi-GPU fits in which this rank's replicated eigenvalues differed from
+ *        rank 0's (rank 0's are used by every rank: one broadcast of 8 Neig bytes). */
+int bigkrls_ctx_get_counters(bigkrls_ctx* ctx, int64_t out[3]);
+
 /* ---- device buffers (replaces bigmemory::big.matrix storage; reference type
  *      BigMatrix / SharedMemoryBigMatrix, e.g. src/gauss_kernel.cpp:34-35) ------ */
 int bigkrls_dev_alloc(bigkrls_ctx* ctx, int64_t nbytes, void** dptr);

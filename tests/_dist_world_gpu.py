@@ -128,6 +128,17 @@ def worker():
         if rank == garbage_rank:
             os.environ["BIGKRLS_FAULT"] = "eig_garbage"
         os.environ["BIGKRLS_REPORT_REDO"] = "1"
+    ulp_rank = int(sys.argv[sys.argv.index("--ulp-rank") + 1]) if "--ulp-rank" in sys.argv else None
+    if ulp_rank is not None:
+        # the test build: ONE rank's copy of the replicated eigenvalues is off by one unit in the last place of one kept
+        # value -- a valid decomposition that passes the check against K. The lock-step lambda search must still see the
+        # same values on every rank (rank 0's are broadcast, csrc/fit.hip): identical lambda, coefficients and
+        # eigenvalues on all ranks, bit for bit, and the deviating rank counts the event
+        import bigkrls_amd._lib as L
+        L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "libbigkrls_hip_fault.so")
+        if rank == ulp_rank:
+            os.environ["BIGKRLS_FAULT"] = "vals_ulp"
+        os.environ["BIGKRLS_REPORT_REDO"] = "1"
     if fault_rank is not None:
         # the test build of the library (fault-injection hooks compiled in); the fault itself only in ONE rank's process
         import bigkrls_amd._lib as L
@@ -180,6 +191,19 @@ def worker():
     out = bkdist.bigKRLS_dist(y, X, comm=comm, timings=T, keep_outputs=True, **kw)
     ctx.sync()
     dt = time.perf_counter() - t0
+    cnt = ctx.counters()
+    replicas_ok = True
+    if ulp_rank is not None:
+        import hashlib
+        os.environ.pop("BIGKRLS_FAULT", None)              # (the single-process fit below is the undisturbed one)
+        mine = (float(out["lambda"]), int(out["lastkeeper"]),
+                hashlib.sha256(np.ascontiguousarray(out["K.eigenvalues"], dtype=np.float64).tobytes()).hexdigest(),
+                hashlib.sha256(np.ascontiguousarray(out["coeffs"], dtype=np.float64).tobytes()).hexdigest())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        replicas_ok = all(e == everyone[0] for e in everyone) and cnt["replica_diff"] == (1 if rank == ulp_rank else 0)
+        print(f"rank {rank}/{world} one-ulp deviation injected in rank {ulp_rank}: replicas "
+              f"{'bitwise identical' if all(e == everyone[0] for e in everyone) else 'DIFFER ' + repr(everyone)}, counters {cnt}", flush=True)
     one = bk.bigKRLS(y, X, ctx=ctx, **kw)
 
     def rel(a, b):
@@ -202,9 +226,10 @@ def worker():
         vc = one["vcov.est.c"]
         vc = vc.to_numpy() if hasattr(vc, "to_numpy") else vc
         checks["vcov.est.c.cols"] = rel(out["vcov.est.c.cols"].to_numpy()[:, : r1 - r0], vc[:, r0:r1])
-    ok = out["lastkeeper"] == one["lastkeeper"] and all(v < 1e-7 for v in checks.values())
+    ok = out["lastkeeper"] == one["lastkeeper"] and all(v < 1e-7 for v in checks.values()) and replicas_ok
     print(f"rank {rank}/{world} N={n} P={p} neig={neig}: {dt:.2f} s lastkeeper {out['lastkeeper']} vs {one['lastkeeper']} "
-          + " ".join(f"{k}={v:.1e}" for k, v in checks.items()) + (" OK" if ok else " MISMATCH"), flush=True)
+          + " ".join(f"{k}={v:.1e}" for k, v in checks.items())
+          + f" [redone={cnt['redone']} replayed={cnt['replayed']} replica_diff={cnt['replica_diff']}]" + (" OK" if ok else " MISMATCH"), flush=True)
     dist.barrier()
     bkdist.release_comms()
     dist.destroy_process_group()
