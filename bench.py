@@ -67,7 +67,7 @@ def parse():
                     help="comma-separated 1-based columns, e.g. 1,3,5")
     ap.add_argument("--cpu-n", type=int, default=None,
                     help="rows of the CPU-baseline sample (default: the bench N for C2/C3)")
-    ap.add_argument("--cpu-budget-s", type=float, default=700.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=800.0,
                     help="wall-clock bound of the CPU baseline; what is measured until then is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -240,6 +240,10 @@ def _compact_entry(e):
     return out
 
 
+TRAFFIC_SOURCE = ("model: algorithmic bytes x the (FETCH_SIZE+WRITE_SIZE)/algorithmic ratio of separate rocprofv3 --pmc "
+                  "passes (profiles/r05/r05u_syrk_traffic_pmc.json, r03/, r02/, r04/), not a counter read in this run")
+
+
 def compact_line(res):
     """The one JSON line in its short form (the driver keeps only the tail of stdout): every definition that used to
     travel as a `note` is in DESIGN.md section 5; `kernel_gemm` -- the GEMM half of BASELINE.json's metric -- sits
@@ -250,9 +254,14 @@ def compact_line(res):
     kg = res.get("kernel_gemm")
     if kg:
         kg = {k: v for k, v in kg.items() if k != "note"}
-    if res.get("roofline"):
-        out["roofline"] = _compact_entry(res["roofline"])
-        out["roofline"]["kernel_gemm"] = kg
+    # `roofline` always exists in the line, and `kernel_gemm` -- half of BASELINE.json's metric -- always with it (also
+    # when no candidate kernel was sampled); a three-number copy stays at the top level for readers of older lines
+    out["roofline"] = _compact_entry(res["roofline"]) if res.get("roofline") else {}
+    out["roofline"]["kernel_gemm"] = kg
+    if out["roofline"].get("traffic") is not None:
+        out["roofline"]["traffic_source"] = res["roofline"].get("traffic_source", TRAFFIC_SOURCE)
+    if kg:
+        out["kernel_gemm"] = {k: kg[k] for k in ("tflops", "hbm_write_gbs", "ms") if k in kg}
     out["other_kernels"] = [_compact_entry(e) for e in res.get("other_kernels", [])]
     cb = res.get("cpu_baseline")
     if cb:

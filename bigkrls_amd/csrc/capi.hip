@@ -98,6 +98,53 @@ int PinnedFetch::finish() {
   return BIGKRLS_OK;
 }
 
+int PinnedStage::reserve(size_t bytes) {
+  if (ctx_->h_stage_bytes < (int64_t)bytes) {
+    BK_HIP(hipStreamSynchronize(ctx_->stream));          // (an earlier call's uploads may still be queued)
+    if (ctx_->h_stage) BK_HIP(hipHostFree(ctx_->h_stage));
+    ctx_->h_stage = nullptr;
+    ctx_->h_stage_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    BK_HIP(hipHostMalloc((void**)&ctx_->h_stage, want, hipHostMallocDefault));
+    ctx_->h_stage_bytes = (int64_t)want;
+  }
+  used_ = fixed_ = 0;
+  return BIGKRLS_OK;
+}
+
+void* PinnedStage::alloc(size_t bytes) {
+  const size_t a = (used_ + 63) & ~(size_t)63;
+  if (!ctx_->h_stage || a + bytes > (size_t)ctx_->h_stage_bytes) return nullptr;
+  used_ = a + bytes;
+  return ctx_->h_stage + a;
+}
+
+void* PinnedStage::fixed(size_t bytes) {
+  void* p = alloc(bytes);
+  if (p) fixed_ = used_;
+  return p;
+}
+
+int PinnedStage::send(void* dev_dst, const void* slice, size_t bytes) {
+  if (bytes == 0) return BIGKRLS_OK;
+  BK_HIP(hipMemcpyAsync(dev_dst, slice, bytes, hipMemcpyHostToDevice, ctx_->stream));
+  return BIGKRLS_OK;
+}
+
+int PinnedStage::put(void* dev_dst, const void* host_src, size_t bytes) {
+  if (bytes == 0) return BIGKRLS_OK;
+  void* p = alloc(bytes);
+  if (!p) {
+    // the arena is full: everything queued so far has to execute before its slices can be reused
+    BK_HIP(hipStreamSynchronize(ctx_->stream));
+    reset();
+    p = alloc(bytes);
+    BK_REQUIRE(p, "PinnedStage: an upload larger than the arena");
+  }
+  std::memcpy(p, host_src, bytes);
+  return send(dev_dst, p, bytes);
+}
+
 int ensure_dyn_smem(bigkrls_ctx* ctx, const void* kernel, size_t bytes) {
   for (const void* k : ctx->dyn_smem_done)
     if (k == kernel) return BIGKRLS_OK;
@@ -318,6 +365,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   (void)bigkrls_ctx_release_workspace(ctx);
   if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

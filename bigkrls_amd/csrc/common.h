@@ -68,6 +68,9 @@ struct bigkrls_ctx {
   // pinned host scratch for small scalar read-backs
   double* h_pinned = nullptr;
   int64_t h_pinned_doubles = 0;
+  // pinned arena the small host -> device uploads of the divide & conquer go through (PinnedStage)
+  char* h_stage = nullptr;
+  int64_t h_stage_bytes = 0;
   // optional HIP-event sampling of named kernels (bench.py roofline numbers)
   bool profile = false;
   struct ProfSample { hipEvent_t e0, e1; double work; };
@@ -195,6 +198,26 @@ class PinnedFetch {
   double* base_ = nullptr;
   size_t used_ = 0;   // doubles
   std::vector<Item> items_;
+};
+
+// Host -> device uploads of small arrays from a pinned arena owned by the context (the reverse of PinnedFetch). An
+// asynchronous copy from pageable memory is staged by the runtime call by call (and is the one runtime path this
+// library has seen misbehave under load); here the source is pinned memory the caller fills in
+// place (alloc) or that put() copies into. A slice stays untouched until reset(), which the caller invokes only after
+// the stream has been synchronised. fixed(): slices that survive reset() (allocated before the first put / alloc).
+class PinnedStage {
+ public:
+  explicit PinnedStage(bigkrls_ctx* ctx) : ctx_(ctx) {}
+  int reserve(size_t bytes);                  // synchronises the stream if the arena has to grow; empties the arena
+  void* fixed(size_t bytes);                  // 64-byte aligned, kept across reset(); nullptr when the arena is full
+  void* alloc(size_t bytes);                  // 64-byte aligned slice of this cycle; nullptr when the arena is full
+  void reset() { used_ = fixed_; }
+  int send(void* dev_dst, const void* slice, size_t bytes);           // slice -> device, asynchronous on ctx->stream
+  int put(void* dev_dst, const void* host_src, size_t bytes);         // copy into a fresh slice, then send
+
+ private:
+  bigkrls_ctx* ctx_;
+  size_t used_ = 0, fixed_ = 0;
 };
 
 // ---- gemm.hip -----------------------------------------------------------------

@@ -944,9 +944,15 @@ struct Node {
 
 // host side of one merge (LAPACK dlaed2's scan, re-derived): fills the packed
 // per-level arrays at offset s.
+// The n-long arrays are slices of the context's pinned upload arena (PinnedStage::fixed), laid out like their device
+// copies -- [dlam | w] and [pole_of_row | srccol | cpos | defsrc | defdst] -- so that a level uploads them with two
+// copies straight from where host_merge wrote them.
 struct LevelArrays {
-  std::vector<double> dlam, w, rc, rs;
-  std::vector<int> rowpos, pole_of_row, srccol, cpos, defsrc, defdst, ra, rb;
+  double *dlam = nullptr, *w = nullptr;
+  int *pole_of_row = nullptr, *srccol = nullptr, *cpos = nullptr, *defsrc = nullptr, *defdst = nullptr;
+  std::vector<int> rowpos;
+  std::vector<double> rc, rs;
+  std::vector<int> ra, rb;
 };
 
 // one level whose merge operators stay factored (see divide_conquer)
@@ -1050,6 +1056,11 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
   }
 }
 
+// pinned upload arena of one decomposition: the level arrays of the divide & conquer + one level's other uploads
+static size_t dc_stage_bytes(int n) {
+  return (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + (size_t)n * 96 + ((size_t)2 << 20);
+}
+
 int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
                    const std::vector<double>& he, double* Q0, double* Q1, double* U,
                    int64_t n_vals, int64_t n_vecs_max, double keep_thresh,
@@ -1099,8 +1110,37 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     if (nodes[id].left >= 0) by_depth[nodes[id].depth].push_back(id);
 
   // ---- device state ---------------------------------------------------------
-  BK_HIP(hipMemsetAsync(Q0, 0, (size_t)N * N * sizeof(double), st));
-  BK_HIP(hipMemsetAsync(Q1, 0, (size_t)N * N * sizeof(double), st));
+  // Few eigenvectors wanted (truncation or Neig << N): the merge operators of the top LAZY_TOP
+  // levels below the root stay factored. Q of depth Dl+1 is the last one formed; above it only the
+  // first and last row of every node's eigenvector matrix (what the parent's z needs) are
+  // propagated, the K x K secular-vector blocks are stashed, and at the end the operators are
+  // applied right-to-left to the N x nv kept columns of the root:
+  //   Q[:, kept] = Q_{Dl+1} M_Dl ... M_1 M_0[:, kept]      (2 K^2 nv flops per merge instead of 2 m K^2).
+  // BIGKRLS_DC=explicit forms every level, =factored forces this path at any size; a root that
+  // keeps more than N/8 columns redoes the divide & conquer explicitly.
+  constexpr int LAZY_TOP = 3;
+  const char* dc_env = getenv("BIGKRLS_DC");
+  const std::string dc_mode = dc_env ? dc_env : "";
+  const bool lazy = allow_lazy && maxdepth - 1 > LAZY_TOP && dc_mode != "explicit" &&
+                    ((n >= 4096 && (keep_thresh > 0.0 || n_vecs_max * 8 <= N)) ||
+                     (dc_mode == "factored" && n >= 128));   // (forced: the tests run small hard spectra)
+  const int Dl = lazy ? LAZY_TOP : -1;
+  // Both copies of Q start as the identity. What is READ of them are the diagonal blocks of the nodes whose eigenvector
+  // matrices are formed explicitly: a merge reads its two children's blocks and the zero blocks between them (rotations
+  // and deflated columns run over the parent's full height) and writes the parent's whole block in the other copy.
+  // With factored top levels the largest such blocks are the depth-Dl nodes' (8 blocks of 2 500^2 at N = 20 000: 0.8 GB
+  // of zeros instead of 6.4 GB, -1.1 ms); without, the whole matrix.
+  if (lazy) {
+    for (const Node& nd : nodes)
+      if (nd.depth == Dl && nd.m > 0) {
+        const int64_t o = nd.s + (int64_t)nd.s * N;
+        BK_HIP(hipMemset2DAsync(Q0 + o, (size_t)N * sizeof(double), 0, (size_t)nd.m * sizeof(double), (size_t)nd.m, st));
+        BK_HIP(hipMemset2DAsync(Q1 + o, (size_t)N * sizeof(double), 0, (size_t)nd.m * sizeof(double), (size_t)nd.m, st));
+      }
+  } else {
+    BK_HIP(hipMemsetAsync(Q0, 0, (size_t)N * N * sizeof(double), st));
+    BK_HIP(hipMemsetAsync(Q1, 0, (size_t)N * N * sizeof(double), st));
+  }
   hipLaunchKernelGGL(dc_init_identity, dim3((n + 255) / 256), dim3(256), 0, st, Q0, n);
   hipLaunchKernelGGL(dc_init_identity, dim3((n + 255) / 256), dim3(256), 0, st, Q1, n);
   BK_CHECK_LAUNCH();
@@ -1142,10 +1182,19 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   double* Qc = Q0;
   double* Qn = Q1;
   std::vector<double> hz(n), hlam(n);
+  // every host -> device upload below goes through the context's pinned arena: the level arrays live in it (uploaded
+  // from where they are written), everything else is copied into a slice of the current level's cycle
+  PinnedStage stage(ctx);
+  BK_TRY(stage.reserve(dc_stage_bytes(n)));
   LevelArrays A;
-  A.dlam.resize(n); A.w.resize(n);
-  A.rowpos.resize(n); A.pole_of_row.resize(n); A.srccol.resize(n); A.cpos.resize(n);
-  A.defsrc.resize(n); A.defdst.resize(n);
+  A.dlam = (double*)stage.fixed((size_t)2 * n * sizeof(double));
+  int* a_int = (int*)stage.fixed((size_t)5 * n * sizeof(int));
+  BK_REQUIRE(A.dlam && a_int, "divide & conquer: pinned arena too small");
+  A.w = A.dlam + n;
+  A.pole_of_row = a_int; A.srccol = a_int + n; A.cpos = a_int + 2 * n; A.defsrc = a_int + 3 * n; A.defdst = a_int + 4 * n;
+  std::memset(A.dlam, 0, (size_t)2 * n * sizeof(double));
+  std::memset(a_int, 0, (size_t)5 * n * sizeof(int));
+  A.rowpos.resize(n);
 
   // ---- leaves larger than 1 x 1: QL on the device, eigenvector blocks into both copies of Q --------
   if (leaf_max > 1) {
@@ -1157,9 +1206,9 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     if (nleaf > 0) {
       int* d_fail = d_iota;                        // (d_iota is filled later, only on the factored path)
       BK_HIP(hipMemsetAsync(d_fail, 0, sizeof(int), st));
-      BK_HIP(hipMemcpyAsync(d_dlam, dadj.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_w, he.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rowpos, lf.data(), lf.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_dlam, dadj.data(), n * sizeof(double)));
+      BK_TRY(stage.put(d_w, he.data(), n * sizeof(double)));
+      BK_TRY(stage.put(d_rowpos, lf.data(), lf.size() * sizeof(int)));
       hipLaunchKernelGGL(dc_leaf_ql, dim3(nleaf), dim3(64), 0, st, (const int2*)d_rowpos, (const double*)d_dlam,
                          (const double*)d_w, Q0, Q1, N, d_lam, d_fail);
       BK_CHECK_LAUNCH();
@@ -1186,21 +1235,6 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
 
   int64_t nv_final = 0;
   const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
-  // Few eigenvectors wanted (truncation or Neig << N): the merge operators of the top LAZY_TOP
-  // levels below the root stay factored. Q of depth Dl+1 is the last one formed; above it only the
-  // first and last row of every node's eigenvector matrix (what the parent's z needs) are
-  // propagated, the K x K secular-vector blocks are stashed, and at the end the operators are
-  // applied right-to-left to the N x nv kept columns of the root:
-  //   Q[:, kept] = Q_{Dl+1} M_Dl ... M_1 M_0[:, kept]      (2 K^2 nv flops per merge instead of 2 m K^2).
-  // BIGKRLS_DC=explicit forms every level, =factored forces this path at any size; a root that
-  // keeps more than N/8 columns redoes the divide & conquer explicitly.
-  constexpr int LAZY_TOP = 3;
-  const char* dc_env = getenv("BIGKRLS_DC");
-  const std::string dc_mode = dc_env ? dc_env : "";
-  const bool lazy = allow_lazy && maxdepth - 1 > LAZY_TOP && dc_mode != "explicit" &&
-                    ((n >= 4096 && (keep_thresh > 0.0 || n_vecs_max * 8 <= N)) ||
-                     (dc_mode == "factored" && n >= 128));   // (forced: the tests run small hard spectra)
-  const int Dl = lazy ? LAZY_TOP : -1;
   std::vector<LazyLevel> lazy_levels(lazy ? Dl + 1 : 0);   // indexed by depth
   std::vector<double> bf, bl, yf, yl;                      // boundary rows of the current frontier / of a level
   double* stash = nullptr;
@@ -1228,7 +1262,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     }
     const bool lazy_level = lazy && depth <= Dl;   // this level's merge operators stay factored
     const bool lazy_kids = lazy && depth < Dl;     // ... and so do the children's eigenvector matrices
-    BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    stage.reset();      // (the previous level ended with a synchronisation: its uploads have executed)
+    BK_TRY(stage.put(d_descs, descs.data(), nm * sizeof(MergeDesc)));
     if (!lazy_kids) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
@@ -1299,21 +1334,18 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       }
     }
     lap(1);
-    BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_dlam, A.dlam.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_w, A.w.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_pole, A.pole_of_row.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_srccol, A.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_defsrc, A.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_defdst, A.defdst.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_TRY(stage.put(d_descs, descs.data(), nm * sizeof(MergeDesc)));
+    // [dlam | w] -> d_dlam, d_w and [pole_of_row | srccol | cpos | defsrc | defdst] -> d_pole ... d_defdst: the device
+    // arrays are laid out the same way (d_cpos receives the host's cpos: no kernel of the level loop reads it)
+    BK_TRY(stage.send(d_dlam, A.dlam, (size_t)2 * n * sizeof(double)));
+    BK_TRY(stage.send(d_pole, A.pole_of_row, (size_t)5 * n * sizeof(int)));
     const int nrot_total = (int)A.ra.size();
     if (nrot_total > 0) {
-      BK_HIP(hipMemcpyAsync(d_ra, A.ra.data(), nrot_total * sizeof(int), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rb, A.rb.data(), nrot_total * sizeof(int), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rc, A.rc.data(), nrot_total * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rs, A.rs.data(), nrot_total * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rotids, rot_merges.data(), rot_merges.size() * sizeof(int),
-                            hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_ra, A.ra.data(), nrot_total * sizeof(int)));
+      BK_TRY(stage.put(d_rb, A.rb.data(), nrot_total * sizeof(int)));
+      BK_TRY(stage.put(d_rc, A.rc.data(), nrot_total * sizeof(double)));
+      BK_TRY(stage.put(d_rs, A.rs.data(), nrot_total * sizeof(double)));
+      BK_TRY(stage.put(d_rotids, rot_merges.data(), rot_merges.size() * sizeof(int)));
       const int nrm = (int)rot_merges.size();
       for (int b0 = 0; b0 < nrm && !lazy_kids; b0 += 65535) {
         const int nb = std::min(65535, nrm - b0);
@@ -1343,8 +1375,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     BK_HIP(hipStreamSynchronize(st));
     lap(3);
     if (trace_fine()) {
-      BK_TRY(trace_host("R:dc_dlam", A.dlam.data(), n, depth));
-      BK_TRY(trace_host("R:dc_w", A.w.data(), n, depth));
+      BK_TRY(trace_host("R:dc_dlam", A.dlam, n, depth));
+      BK_TRY(trace_host("R:dc_w", A.w, n, depth));
       BK_TRY(trace_host("R:dc_roots", hlam.data(), n, maxK));
     }
     // new eigenvalue lists in storage order
@@ -1367,9 +1399,20 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     }
     if (is_root) {
       const Node& P = nodes[ids[0]];
+      // descending order of all n values, ties in storage order (= a stable sort of the indices): the K roots are stored
+      // in descending order already, so only the deflated tail is sorted and the two runs are merged
       std::vector<int> ord(n);
       std::iota(ord.begin(), ord.end(), 0);
-      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.dv[a] > P.dv[b]; });
+      {
+        auto desc = [&](int a, int b) { return P.dv[a] > P.dv[b]; };
+        const int Kr = descs[0].K;
+        if (std::is_sorted(ord.begin(), ord.begin() + Kr, desc)) {
+          std::stable_sort(ord.begin() + Kr, ord.end(), desc);
+          std::inplace_merge(ord.begin(), ord.begin() + Kr, ord.end(), desc);
+        } else {
+          std::stable_sort(ord.begin(), ord.end(), desc);
+        }
+      }
       vals_desc.resize(n);
       for (int t = 0; t < n; ++t) vals_desc[t] = P.dv[ord[t]];
       int64_t nv = n_vecs_max;
@@ -1394,7 +1437,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         return divide_conquer(ctx, n, hd, he, Q0, Q1, U, n_vals, n_vecs_max, keep_thresh, vals_desc,
                               src_cols, Qfinal, false);
       }
-      BK_HIP(hipMemcpyAsync(d_descs, descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_descs, descs.data(), nm * sizeof(MergeDesc)));
     }
     // eigenvector update
     int maxKneed = 0;
@@ -1417,7 +1460,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     if (lazy_level) {
       LazyLevel& L = lazy_levels[depth];
       L.descs = descs;
-      L.srccol = A.srccol; L.defsrc = A.defsrc;
+      L.srccol.assign(A.srccol, A.srccol + n);
+      L.defsrc.assign(A.defsrc, A.defsrc + n);
       L.max_m = max_m; L.maxK = maxK;
       if (lazy_kids) {   // (at depth Dl the rotations went into the explicit Q of depth Dl+1)
         L.ra = A.ra; L.rb = A.rb; L.rc = A.rc; L.rs = A.rs; L.rot_merges = rot_merges;
@@ -1443,8 +1487,8 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
             glh[md.s + i] = yl[md.s + A.srccol[md.s + i]];
           }
         }
-        BK_HIP(hipMemcpyAsync(d_gf, gfh.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-        BK_HIP(hipMemcpyAsync(d_gl, glh.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        BK_TRY(stage.put(d_gf, gfh.data(), n * sizeof(double)));
+        BK_TRY(stage.put(d_gl, glh.data(), n * sizeof(double)));
         if (maxK > 0) {
           for (int b0 = 0; b0 < nm; b0 += 65535) {
             const int nb = std::min(65535, nm - b0);
@@ -1500,7 +1544,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       const bool dc_lag = dc_fault && (std::string(dc_fault) == "dc_lag" || std::string(dc_fault) == "dc_gd_clobber");
       if (dc_lag) hipLaunchKernelGGL(dc_fault_spin, dim3(1), dim3(64), 0, st, 200000LL);
 #endif
-      BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc)));
       BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, gn));
 #ifdef BK_FAULT_INJECT
       if (dc_fault && std::string(dc_fault) == "dc_gd_clobber") std::memset((void*)gd.data(), 0, gd.size() * sizeof(GemmDesc));
@@ -1551,10 +1595,11 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     double* Xa = U + N * (int64_t)kc;
     double* Xb = Xa + N * (int64_t)nv;
     double* Tm = Xb + N * (int64_t)nv;
+    stage.reset();      // (the root level ended with a synchronisation)
     BK_HIP(hipMemsetAsync(Xa, 0, (size_t)N * nv * sizeof(double), st));
-    BK_HIP(hipMemcpyAsync(d_cpos, src_cols.data(), nv * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_srccol, R.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    BK_HIP(hipMemcpyAsync(d_defsrc, R.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_TRY(stage.put(d_cpos, src_cols.data(), nv * sizeof(int)));
+    BK_TRY(stage.put(d_srccol, R.srccol.data(), n * sizeof(int)));
+    BK_TRY(stage.put(d_defsrc, R.defsrc.data(), n * sizeof(int)));
     hipLaunchKernelGGL(dc_iota, dim3((n + 255) / 256), dim3(256), 0, st, d_iota, n);
     hipLaunchKernelGGL(dc_lazy_root_x, dim3(nv), dim3(256), 0, st, nv, (const int*)d_cpos, K0,
                        (const int*)d_srccol, (const int*)d_defsrc, (const double*)U, N, Xa, N);
@@ -1562,29 +1607,28 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     auto apply_rotations = [&](const LazyLevel& L, double* X) -> int {
       if (L.ra.empty() || L.rot_merges.empty()) return BIGKRLS_OK;
       const int nrt = (int)L.ra.size(), nrm = (int)L.rot_merges.size();
-      BK_HIP(hipMemcpyAsync(d_ra, L.ra.data(), nrt * sizeof(int), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rb, L.rb.data(), nrt * sizeof(int), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rc, L.rc.data(), nrt * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rs, L.rs.data(), nrt * sizeof(double), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_rotids, L.rot_merges.data(), nrm * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_ra, L.ra.data(), nrt * sizeof(int)));
+      BK_TRY(stage.put(d_rb, L.rb.data(), nrt * sizeof(int)));
+      BK_TRY(stage.put(d_rc, L.rc.data(), nrt * sizeof(double)));
+      BK_TRY(stage.put(d_rs, L.rs.data(), nrt * sizeof(double)));
+      BK_TRY(stage.put(d_rotids, L.rot_merges.data(), nrm * sizeof(int)));
       hipLaunchKernelGGL(dc_lazy_rotate, dim3((nv + 63) / 64, nrm), dim3(64), 0, st,
                          (const MergeDesc*)d_descs, (const int*)d_rotids, (const int*)d_ra,
                          (const int*)d_rb, (const double*)d_rc, (const double*)d_rs, X, N, nv);
       BK_CHECK_LAUNCH();
       return BIGKRLS_OK;
     };
-    BK_HIP(hipMemcpyAsync(d_descs, R.descs.data(), sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+    BK_TRY(stage.put(d_descs, R.descs.data(), sizeof(MergeDesc)));
     BK_TRY(apply_rotations(R, Xa));
-    BK_HIP(hipStreamSynchronize(st));
     double* cur = Xa;
     double* oth = Xb;
     std::vector<GemmDesc> gd;
     for (int d = 1; d <= Dl; ++d) {
       const LazyLevel& L = lazy_levels[d];
       const int nm = (int)L.descs.size();
-      BK_HIP(hipMemcpyAsync(d_descs, L.descs.data(), nm * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_srccol, L.srccol.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-      BK_HIP(hipMemcpyAsync(d_defsrc, L.defsrc.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_descs, L.descs.data(), nm * sizeof(MergeDesc)));
+      BK_TRY(stage.put(d_srccol, L.srccol.data(), n * sizeof(int)));
+      BK_TRY(stage.put(d_defsrc, L.defsrc.data(), n * sizeof(int)));
       gd.clear();
       for (int q = 0; q < nm; ++q) {
         const MergeDesc& md = L.descs[q];
@@ -1596,15 +1640,14 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         gd.push_back(g);
       }
       if (!gd.empty()) {
-        BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+        BK_TRY(stage.put(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc)));
         BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), L.maxK, nv));
       }
       hipLaunchKernelGGL(dc_lazy_scatter, dim3((L.max_m + 255) / 256, nm, nv), dim3(256), 0, st,
                          (const MergeDesc*)d_descs, (const int*)d_srccol, (const int*)d_defsrc,
                          (const double*)Tm, (const double*)cur, oth, N);
       BK_CHECK_LAUNCH();
-      BK_TRY(apply_rotations(L, oth));
-      BK_HIP(hipStreamSynchronize(st));   // the host vectors were sources of asynchronous copies
+      BK_TRY(apply_rotations(L, oth));    // (every upload has its own slice of the pinned arena: no synchronisation here)
       std::swap(cur, oth);
     }
     // the explicit eigenvector matrices of depth Dl+1, one block per depth-Dl merge: that level's
@@ -1621,7 +1664,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         gd.push_back(g);
         gm = std::max(gm, md.m);
       }
-      BK_HIP(hipMemcpyAsync(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+      BK_TRY(stage.put(d_gdescs, gd.data(), gd.size() * sizeof(GemmDesc)));
       BK_TRY(gemm_batched_nn(ctx, d_gdescs, (int)gd.size(), gm, nv));
       BK_HIP(hipStreamSynchronize(st));
     }
@@ -2519,8 +2562,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     BK_TRY(ws_get(ctx, SLOT_EIG_VV, (plan.nrefl * (S2_B + 1) + 16) * sizeof(double), &pvv));
     VV = (double*)pvv;
     TT = VV + plan.nrefl * S2_B;
-    BK_HIP(hipMemcpyAsync(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t),
-                          hipMemcpyHostToDevice, st));
+    {
+      // (through the pinned upload arena, sized here for the whole decomposition so that it is not reallocated later)
+      PinnedStage up(ctx);
+      BK_TRY(up.reserve(std::max(dc_stage_bytes(n), plan.soff.size() * sizeof(int64_t) + 4096)));
+      BK_TRY(up.put(d_soff, plan.soff.data(), plan.soff.size() * sizeof(int64_t)));
+    }
     if (mode != EIG_RESUME) BK_HIP(hipMemsetAsync(taus1, 0, 2 * N * sizeof(double), st));
     if ((mode == EIG_FULL || mode == EIG_SETUP_ONLY) && n >= S1_AGG_MIN_M + 4 * S2_B) {
       // reflector blocks of the two panel groups whose trailing update is pending (stage1_to_band)
@@ -2672,14 +2719,16 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
   if (trace_on()) {
     BK_TRY(trace_host("R:eig_vals", vals_desc.data(), n_vals, (int64_t)src_cols.size()));
   }
-  BK_HIP(hipMemcpyAsync(vals, vals_desc.data(), n_vals * sizeof(double), hipMemcpyHostToDevice, st));
+  PinnedStage up(ctx);      // (the divide & conquer ended with a synchronisation: the arena is free)
+  BK_TRY(up.reserve((size_t)n_vals * sizeof(double) + (size_t)n * sizeof(int) + 4096));
+  BK_TRY(up.put(vals, vals_desc.data(), n_vals * sizeof(double)));
   const int nv = (int)src_cols.size();
   if (h_n_vecs) *h_n_vecs = nv;
   if (nv > 0 && n_vecs_max > 0) {
     void* pidx = nullptr;
     BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)10 * n * sizeof(int), &pidx));
     int* d_src = (int*)pidx;
-    BK_HIP(hipMemcpyAsync(d_src, src_cols.data(), nv * sizeof(int), hipMemcpyHostToDevice, st));
+    BK_TRY(up.put(d_src, src_cols.data(), nv * sizeof(int)));
     int blocks = (int)std::min<int64_t>((N * nv + 255) / 256, 8192);
     hipLaunchKernelGGL(gather_cols, dim3(blocks), dim3(256), 0, st, n, nv, (const int*)d_src,
                        (const double*)Qfin, N, vecs, ldv);

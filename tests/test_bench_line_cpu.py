@@ -34,6 +34,26 @@ def test_compact_line_keeps_the_contract_and_stays_small():
     assert all(set(p) >= {"kernel", "frac", "total_ms_per_fit"} for p in roof.get("parts", []))
 
 
+def test_compact_line_without_a_sampled_roofline_still_carries_the_kernel_gemm():
+    """No candidate kernel sampled (roofline = None): the line keeps a `roofline` object with `kernel_gemm` in it, and the
+    short top-level copy."""
+    import bench
+    long_form = json.load(open(os.path.join(ROOT, "profiles", "r04", "r04z_bench_C3_default_with_cpu_baseline.json")))
+    kg = long_form["kernel_gemm"]
+    long_form["roofline"] = None
+    line = bench.compact_line(long_form)
+    assert line["roofline"]["kernel_gemm"]["tflops"] == kg["tflops"]
+    assert line["kernel_gemm"]["tflops"] == kg["tflops"] and line["kernel_gemm"]["ms"] == kg["ms"]
+    assert "traffic_source" not in line["roofline"]
+
+
+def test_compact_line_says_where_the_traffic_figure_comes_from():
+    import bench
+    long_form = json.load(open(os.path.join(ROOT, "profiles", "r04", "r04z_bench_C3_default_with_cpu_baseline.json")))
+    line = bench.compact_line(long_form)
+    assert line["roofline"]["traffic"] is not None and line["roofline"]["traffic_source"].startswith("model:")
+
+
 def test_cpu_baseline_object_is_assembled_from_the_child_lines_and_fits_the_line():
     """CpuBaseline.collect() on recorded child output (no child process, no GPU): the required keys, the share of
     `value` that is scaled from timed samples, and the whole compact line still under 6 KB with it."""
