@@ -40,6 +40,7 @@ int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out) {
       return BIGKRLS_ENOMEM;
     }
     ctx->ws_bytes[slot] = want;
+    ctx->ws_generation++;
     // BIGKRLS_POISON=1 (diagnostics): a fresh slab starts as all-ones bytes (NaN as a double, -1 as an index), so that
     // anything read before it is written shows up at once instead of depending on what the memory held before
     if (ws_poison()) {   // (on the context's stream: hipMemset runs on the NULL stream, asynchronously to the host)
@@ -175,6 +176,7 @@ int side_stream_get(bigkrls_ctx* ctx) {
       BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
       BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
       BK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+      BK_HIP(hipEventCreateWithFlags(&ctx->ev_pq, hipEventDisableTiming));
       return BIGKRLS_OK;
     }
     // highest priority: its short latency-bound launches must not queue behind the thousands of
@@ -185,6 +187,7 @@ int side_stream_get(bigkrls_ctx* ctx) {
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+    BK_HIP(hipEventCreateWithFlags(&ctx->ev_pq, hipEventDisableTiming));
   }
   return BIGKRLS_OK;
 }
@@ -356,13 +359,18 @@ int bigkrls_ctx_release_workspace(bigkrls_ctx* ctx) {
     ctx->ws[i] = nullptr;
     ctx->ws_bytes[i] = 0;
   }
+  ctx->ws_generation++;
+  if (ctx->s1_graph_exec) {        // (points into the workspace that has just gone)
+    (void)hipGraphExecDestroy((hipGraphExec_t)ctx->s1_graph_exec);
+    ctx->s1_graph_exec = nullptr;
+  }
   return BIGKRLS_OK;
 }
 
 int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (!ctx) return BIGKRLS_OK;
   (void)hipSetDevice(ctx->device);
-  (void)bigkrls_ctx_release_workspace(ctx);
+  (void)bigkrls_ctx_release_workspace(ctx);      // (also drops the captured stage-1 graph)
   if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -371,6 +379,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+  if (ctx->ev_pq) (void)hipEventDestroy(ctx->ev_pq);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return BIGKRLS_OK;

@@ -60,7 +60,7 @@ struct bigkrls_ctx {
   void (*dist_s1_free)(void*) = nullptr;
   hipStream_t side_stream = nullptr;
   bool side_is_main = false;   // BIGKRLS_NO_SIDE (diagnostics): side_stream is the main stream itself
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_pq = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls
   static constexpr int kSlots = 48;
   void* ws[kSlots] = {nullptr};
@@ -85,6 +85,15 @@ struct bigkrls_ctx {
   // input (a block recurrence that does not hold against K, non-finite entries after the tridiagonalisation); read and
   // cleared by the fit, which validated its input and redoes such a decomposition once (csrc/fit.hip)
   bool corrupt_run = false;
+  // device-side predicate of the next gemm() launches (kernel and split-K reduction return at once while *gemm_run_if
+  // == 0): the T-factor chain of a stage-1 panel only runs when pq_chol left the panel to the Householder kernel
+  const int* gemm_run_if = nullptr;
+  // BIGKRLS_S1_GRAPH (experiment, csrc/eigen.hip): the stage-1 panel loop of the last size, captured as a hipGraph; valid
+  // while the workspace it points into has not been reallocated (ws_generation)
+  void* s1_graph_exec = nullptr;
+  int s1_graph_n = 0, s1_graph_warm_n = 0;
+  int64_t s1_graph_gen = -1, ws_generation = 0;
+  const void* s1_graph_W = nullptr;
 };
 
 // One rank of a multi-GPU job (one process per GPU): the context it computes on and the collectives that connect

@@ -1701,7 +1701,8 @@ __global__ void bt_extract_panel(const double* __restrict__ W, int n, int j0, in
 // T (pw x pw upper triangular) from G = Vp'Vp and tau (LAPACK dlarft, forward/columnwise)
 __global__ __launch_bounds__(256) void bt_build_t(const double* __restrict__ G, int pw,
                                                   const double* __restrict__ tau,
-                                                  double* __restrict__ T) {
+                                                  double* __restrict__ T, const int* __restrict__ run_if) {
+  if (run_if != nullptr && *run_if == 0) return;    // (a stage-1 panel whose T factor pq_chol has already written)
   // Blocked recurrence: the four 16 x 16 diagonal blocks of T are built at the same time (one wave
   // each, 16 dependent column steps: T[0:i, i] = -tau_i T[0:i,0:i] G[0:i, i] inside the block),
   // then block column j = 1, 2, 3 follows from T(0:16j, j) = -T(0:16j, 0:16j) G(0:16j, j) T_jj
@@ -1778,7 +1779,7 @@ int back_transform(bigkrls_ctx* ctx, const double* W, int n, const double* tau, 
     hipLaunchKernelGGL(bt_extract_panel, dim3(blocks), dim3(256), 0, st, W, n, j0, pw, Vp, ne);
     BK_CHECK_LAUNCH();
     BK_TRY(gemm(ctx, 1, 0, pw, pw, ne, 1.0, Vp, ne, Vp, ne, 0.0, G, pw));
-    hipLaunchKernelGGL(bt_build_t, dim3(1), dim3(256), 0, st, (const double*)G, pw, tau + j0, T);
+    hipLaunchKernelGGL(bt_build_t, dim3(1), dim3(256), 0, st, (const double*)G, pw, tau + j0, T, (const int*)nullptr);
     BK_CHECK_LAUNCH();
     double* Zs = Z + (j0 + 1);
     BK_TRY(gemm(ctx, 1, 0, pw, nv, ne, 1.0, Vp, ne, Zs, ldz, 0.0, W1, pw));
@@ -2410,6 +2411,77 @@ struct DistS1 {
   int agg_mode = 0;             // panels per trailing update the ranks agreed on: 4 (groups of four, then pairs), 2 (pairs), 0 (none)
 };
 
+// BIGKRLS_S1_GRAPH (experiment; off by default): the stage-1 panel loop as a captured hipGraph. The loop has no host
+// synchronisation and no host decision that depends on device data -- every launch dimension follows from n -- and its two
+// streams meet only through ev_fork / ev_join / ev_join2, the fork-join shape stream capture accepts. The first
+// decomposition of a size on a context runs uncaptured (workspace growth, hipFuncSetAttribute and the side stream's
+// creation must not happen inside a capture); from the second on the loop is captured once, instantiated, and the
+// executable graph replayed for as long as the workspace it points into has not moved (ctx->ws_generation).
+//   =1: capture + instantiate + launch at every call, the three timed (BIGKRLS_VERBOSE)   =2: cached executable graph
+static int stage1_run(bigkrls_ctx* ctx, double* W, int n, double* taus1, const Stage1Ws& s1) {
+  static const int gmode = [] { const char* e = getenv("BIGKRLS_S1_GRAPH"); return e ? atoi(e) : 0; }();
+  if (gmode <= 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main)
+    return stage1_to_band(ctx, W, n, taus1, s1);
+  if (ctx->s1_graph_warm_n != n) {
+    ctx->s1_graph_warm_n = n;
+    return stage1_to_band(ctx, W, n, taus1, s1);
+  }
+  hipStream_t st = ctx->stream;
+  const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const bool hit = gmode >= 2 && ctx->s1_graph_exec && ctx->s1_graph_n == n && ctx->s1_graph_gen == ctx->ws_generation &&
+                   ctx->s1_graph_W == (const void*)W;
+  const auto t0 = now();
+  if (!hit) {
+    if (ctx->s1_graph_exec) {
+      BK_HIP(hipStreamSynchronize(st));
+      (void)hipGraphExecDestroy((hipGraphExec_t)ctx->s1_graph_exec);
+      ctx->s1_graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    BK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    const int rc = stage1_to_band(ctx, W, n, taus1, s1);
+    const hipError_t ec = hipStreamEndCapture(st, &graph);      // (always: the stream must leave capture mode)
+    if (rc != BIGKRLS_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    if (ec != hipSuccess || !graph) {
+      set_error(std::string("stage 1: stream capture failed: ") + hipGetErrorString(ec));
+      return BIGKRLS_EHIP;
+    }
+    const auto t1 = now();
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    size_t nnodes = 0;
+    (void)hipGraphGetNodes(graph, nullptr, &nnodes);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) {
+      set_error(std::string("stage 1: hipGraphInstantiate failed: ") + hipGetErrorString(ei));
+      return BIGKRLS_EHIP;
+    }
+    ctx->s1_graph_exec = (void*)exec;
+    ctx->s1_graph_n = n;
+    ctx->s1_graph_gen = ctx->ws_generation;
+    ctx->s1_graph_W = (const void*)W;
+    if (verbose)
+      fprintf(stderr, "[bigkrls]   stage 1 as a graph: %zu nodes, capture %.2f ms, instantiate %.2f ms\n", nnodes, ms(t0, t1),
+              ms(t1, now()));
+  }
+  const auto t2 = now();
+  BK_HIP(hipGraphLaunch((hipGraphExec_t)ctx->s1_graph_exec, st));
+  if (verbose) {
+    const auto t3 = now();
+    BK_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "[bigkrls]   stage 1 as a graph: launch call %.2f ms, launch to completion %.2f ms%s\n", ms(t2, t3),
+            ms(t2, now()), hit ? " (cached executable graph)" : "");
+  }
+  return BIGKRLS_OK;
+}
+
 int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n_vals, double* vals,
           int64_t n_vecs_max, double keep_thresh, double* vecs, int64_t ldv, int64_t* h_n_vecs,
           int part_index, int part_count, int mode) {
@@ -2591,7 +2663,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       return BIGKRLS_OK;
     }
     tick("setup + copy");
-    if (mode == EIG_FULL) BK_TRY(stage1_to_band(ctx, W, n, taus1, s1));
+    if (mode == EIG_FULL) BK_TRY(stage1_run(ctx, W, n, taus1, s1));
     if (mode == EIG_FULL && getenv("BIGKRLS_VERBOSE") && s1.pqc) {
       double nfb = 0.0;
       PinnedFetch pfb(ctx, 1);       // (never a device -> pageable copy: the runtime would pin / unpin the page)

@@ -151,6 +151,7 @@ struct GemmOperands {
   int64_t lda, ldb;
   int M, N, K;
   const int* kidx;  // optional gather of A's columns (NN only): op(A)(:,k) = A(:, kidx[k])
+  const int* run_if = nullptr;  // optional device-side predicate (plain GEMM kernels only): nothing is done while *run_if == 0
 };
 
 // Computes the accumulators of the (m0, n0) block tile over k in [kbeg, kend).
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(NT, (gemm_occ<TA, TB, BN>())) void gemm_kernel(Gemm
                                                   int tiles_m, int tiles_n, int k_chunk,
                                                   double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (g.run_if != nullptr && *g.run_if == 0) return;      // (uniform: a scalar load)
   const int ntile = tiles_m * tiles_n;
   const int tid = xcd_remap(blockIdx.x, ntile);
   const int tm = tid % tiles_m, tn = tid / tiles_m;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(NT, (gemm_occ<TA, TB, BN>())) void gemm_kernel(Gemm
 
 __global__ void splitk_reduce_kernel(const double* __restrict__ partial, int splits, int M, int N,
                                      double alpha, double beta, double* __restrict__ C,
-                                     int64_t ldc) {
+                                     int64_t ldc, const int* __restrict__ run_if) {
+  if (run_if != nullptr && *run_if == 0) return;
   // slabs are summed in the fixed order z = 0, 1, ... (deterministic); the loads of four slabs are
   // issued together -- with one load in flight per thread the kernel is latency-bound
   const int64_t total = (int64_t)M * N;
@@ -505,7 +508,7 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, partial,
-                       splits, g.M, g.N, alpha, beta, C, ldc);
+                       splits, g.M, g.N, alpha, beta, C, ldc, g.run_if);
     BK_CHECK_LAUNCH();
   }
   return BIGKRLS_OK;
@@ -544,7 +547,7 @@ int gemm(bigkrls_ctx* ctx, int ta, int tb, int64_t m, int64_t n, int64_t k, doub
     return BIGKRLS_OK;
   }
   BK_REQUIRE(A && B && C, "gemm: null pointer");
-  GemmOperands g{A, B, lda, ldb, (int)m, (int)n, (int)k, nullptr};
+  GemmOperands g{A, B, lda, ldb, (int)m, (int)n, (int)k, nullptr, ctx->gemm_run_if};
   if (n <= 32) return dispatch_trans<32>(ctx, ta, tb, g, alpha, beta, C, ldc);
   if (n <= 64) return dispatch_trans<64>(ctx, ta, tb, g, alpha, beta, C, ldc);
   return dispatch_trans<128>(ctx, ta, tb, g, alpha, beta, C, ldc);
@@ -678,7 +681,7 @@ int gemm_nn_skinny48(bigkrls_ctx* ctx, int64_t m, int64_t n, int64_t k, const do
   BK_CHECK_LAUNCH();
   int blocks = (int)std::min<int64_t>((m * n + 255) / 256, 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)p, splits, (int)m, (int)n,
-                     1.0, 0.0, C, ldc);
+                     1.0, 0.0, C, ldc, (const int*)nullptr);
   BK_CHECK_LAUNCH();
   return BIGKRLS_OK;
 }
