@@ -600,6 +600,19 @@ __global__ __launch_bounds__(64) void dc_leaf_ql(const int2* __restrict__ leaves
   }
 }
 
+// zero the m x m diagonal blocks (s, m) = blocks[b] of both copies of Q: one workgroup per block column (16-byte stores
+// where the column start allows; the 2-D memset of the runtime took as long as zeroing the whole matrices)
+__global__ __launch_bounds__(256) void dc_zero_blocks(const int2* __restrict__ blocks, double* __restrict__ Q0,
+                                                      double* __restrict__ Q1, int64_t ld) {
+  const int2 sm = blocks[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= sm.y) return;
+  const int64_t o = sm.x + (int64_t)(sm.x + c) * ld;
+  double* a = Q0 + o;
+  double* b = Q1 + o;
+  for (int r = threadIdx.x; r < sm.y; r += 256) { a[r] = 0.0; b[r] = 0.0; }
+}
+
 __global__ void dc_init_identity(double* __restrict__ Q, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) Q[(int64_t)i * n + i] = 1.0;
@@ -1110,6 +1123,18 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     if (nodes[id].left >= 0) by_depth[nodes[id].depth].push_back(id);
 
   // ---- device state ---------------------------------------------------------
+  // every host -> device upload below goes through the context's pinned arena: the level arrays live in it (uploaded
+  // from where they are written), everything else is copied into a slice of the current level's cycle
+  PinnedStage stage(ctx);
+  BK_TRY(stage.reserve(dc_stage_bytes(n)));
+  LevelArrays A;
+  A.dlam = (double*)stage.fixed((size_t)2 * n * sizeof(double));
+  int* a_int = (int*)stage.fixed((size_t)5 * n * sizeof(int));
+  BK_REQUIRE(A.dlam && a_int, "divide & conquer: pinned arena too small");
+  A.w = A.dlam + n;
+  A.pole_of_row = a_int; A.srccol = a_int + n; A.cpos = a_int + 2 * n; A.defsrc = a_int + 3 * n; A.defdst = a_int + 4 * n;
+  std::memset(A.dlam, 0, (size_t)2 * n * sizeof(double));
+  std::memset(a_int, 0, (size_t)5 * n * sizeof(int));
   // Few eigenvectors wanted (truncation or Neig << N): the merge operators of the top LAZY_TOP
   // levels below the root stay factored. Q of depth Dl+1 is the last one formed; above it only the
   // first and last row of every node's eigenvector matrix (what the parent's z needs) are
@@ -1130,13 +1155,22 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   // and deflated columns run over the parent's full height) and writes the parent's whole block in the other copy.
   // With factored top levels the largest such blocks are the depth-Dl nodes' (8 blocks of 2 500^2 at N = 20 000: 0.8 GB
   // of zeros instead of 6.4 GB, -1.1 ms); without, the whole matrix.
-  if (lazy) {
+  std::vector<int> zb;       // (s, m) of the depth-Dl nodes
+  if (lazy)
     for (const Node& nd : nodes)
-      if (nd.depth == Dl && nd.m > 0) {
-        const int64_t o = nd.s + (int64_t)nd.s * N;
-        BK_HIP(hipMemset2DAsync(Q0 + o, (size_t)N * sizeof(double), 0, (size_t)nd.m * sizeof(double), (size_t)nd.m, st));
-        BK_HIP(hipMemset2DAsync(Q1 + o, (size_t)N * sizeof(double), 0, (size_t)nd.m * sizeof(double), (size_t)nd.m, st));
-      }
+      if (nd.depth == Dl && nd.m > 0) { zb.push_back(nd.s); zb.push_back(nd.m); }
+  if (lazy && !zb.empty()) {
+    // (the list goes up through the integer workspace of the levels, which is first used after the leaves)
+    void* pzi = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_EIG_INT, (int64_t)11 * n * sizeof(int), &pzi));
+    int* zlist = (int*)stage.fixed(zb.size() * sizeof(int));     // (a slice that no later upload of this call reuses)
+    BK_REQUIRE(zlist, "divide & conquer: pinned arena too small");
+    std::memcpy(zlist, zb.data(), zb.size() * sizeof(int));
+    BK_TRY(stage.send(pzi, zlist, zb.size() * sizeof(int)));
+    int zmax = 0;
+    for (size_t i = 1; i < zb.size(); i += 2) zmax = std::max(zmax, zb[i]);
+    hipLaunchKernelGGL(dc_zero_blocks, dim3(zmax, (unsigned)(zb.size() / 2)), dim3(256), 0, st, (const int2*)pzi, Q0, Q1, N);
+    BK_CHECK_LAUNCH();
   } else {
     BK_HIP(hipMemsetAsync(Q0, 0, (size_t)N * N * sizeof(double), st));
     BK_HIP(hipMemsetAsync(Q1, 0, (size_t)N * N * sizeof(double), st));
@@ -1182,19 +1216,6 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   double* Qc = Q0;
   double* Qn = Q1;
   std::vector<double> hz(n), hlam(n);
-  // every host -> device upload below goes through the context's pinned arena: the level arrays live in it (uploaded
-  // from where they are written), everything else is copied into a slice of the current level's cycle
-  PinnedStage stage(ctx);
-  BK_TRY(stage.reserve(dc_stage_bytes(n)));
-  LevelArrays A;
-  A.dlam = (double*)stage.fixed((size_t)2 * n * sizeof(double));
-  int* a_int = (int*)stage.fixed((size_t)5 * n * sizeof(int));
-  BK_REQUIRE(A.dlam && a_int, "divide & conquer: pinned arena too small");
-  A.w = A.dlam + n;
-  A.pole_of_row = a_int; A.srccol = a_int + n; A.cpos = a_int + 2 * n; A.defsrc = a_int + 3 * n; A.defdst = a_int + 4 * n;
-  std::memset(A.dlam, 0, (size_t)2 * n * sizeof(double));
-  std::memset(a_int, 0, (size_t)5 * n * sizeof(int));
-  A.rowpos.resize(n);
 
   // ---- leaves larger than 1 x 1: QL on the device, eigenvector blocks into both copies of Q --------
   if (leaf_max > 1) {
@@ -2420,7 +2441,8 @@ struct DistS1 {
 //   =1: capture + instantiate + launch at every call, the three timed (BIGKRLS_VERBOSE)   =2: cached executable graph
 static int stage1_run(bigkrls_ctx* ctx, double* W, int n, double* taus1, const Stage1Ws& s1) {
   static const int gmode = [] { const char* e = getenv("BIGKRLS_S1_GRAPH"); return e ? atoi(e) : 0; }();
-  if (gmode <= 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main)
+  // (the process's default stream cannot be captured: contexts on it keep the plain loop)
+  if (gmode <= 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main || ctx->stream == nullptr)
     return stage1_to_band(ctx, W, n, taus1, s1);
   if (ctx->s1_graph_warm_n != n) {
     ctx->s1_graph_warm_n = n;
@@ -3000,6 +3022,7 @@ int dist_s1_update_cols(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Acols, i
   BK_REQUIRE(m > 0 && ncols >= 0 && row0 >= 0 && row0 + ncols <= m, "s1_update_cols: bad arguments");
   if (ncols == 0) return BIGKRLS_OK;
   BK_REQUIRE(Acols && lda >= m, "s1_update_cols: bad column block");
+  if (ds->panel_pending) BK_TRY(ds->ops.gate());   // (the next panel's factorisation, on the look-ahead stream, becomes resident first)
   const double *PZ1 = ds->ops.ws.PZ1, *PZ2 = ds->ops.ws.PZ2;
   // The own columns' diagonal block (rows row0 .. row0 + ncols of the trailing matrix) is symmetric: lower tiles
   // computed and mirrored (half the MFMA work of the plain product; with one rank that is the whole update);
@@ -3083,6 +3106,7 @@ int dist_s1_update_cols_group(bigkrls_ctx* ctx, int64_t n, int64_t k, double* Ac
                  off / b < nblk && ds->ops.ws.aggPZ1[0], "s1_update_cols_group: bad arguments");
   if (ncols == 0) return BIGKRLS_OK;
   BK_REQUIRE(Acols && lda >= m, "s1_update_cols_group: bad column block");
+  if (ds->panel_pending) BK_TRY(ds->ops.gate());   // (see dist_s1_update_cols)
   const int64_t ldg = ds->ops.ws.aggLd, kk = 2 * b * nblk;
   const double *PZ1 = ds->ops.ws.aggPZ1[0] + off, *PZ2 = ds->ops.ws.aggPZ1[1] + off;
   if (ncols >= 128) {

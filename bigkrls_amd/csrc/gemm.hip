@@ -758,17 +758,18 @@ struct SyrkMap {
 #define SYRK64_DEEP 0
 #endif
 #ifndef SYRK64_LDS_EXACT
-#define SYRK64_LDS_EXACT 0
+#define SYRK64_LDS_EXACT 1
 #endif
 template <int BN, bool ACCUM = true>
 __global__ __launch_bounds__(NT, (BN == 64 ? SYRK64_OCC : GEMM_OCC)) void syrk_mirror_kernel(
     GemmOperands g, double alpha, double* __restrict__ C, int64_t ldc, SyrkMap map) {
-  // Tiles are 128 x BN. BN = 64 halves the accumulators; its 154 VGPRs would let THREE workgroups share a CU, and with
-  // the layout-exact 52 KB of LDS (SYRK64_LDS_EXACT) they do: 5-7% faster in isolation (m = 20 000: k = 128 1 817 ->
-  // 1 693 us, k = 256 2 404 -> 2 286). The fit keeps the 54 KB request (lds_stage(), room for either layout), i.e. TWO
-  // per CU: the panel QR of the next panel runs beside this kernel, its workgroups need 105 KB of LDS and 256 VGPRs,
-  // and with three of these per CU a finished one leaves a hole they do not fit into -- the QR then starts late on
-  // the critical path (C3 fit 0.469 -> 0.511 s; profiles/r03/r03m_*).
+  // Tiles are 128 x BN. BN = 64 halves the accumulators; its 154 VGPRs let THREE workgroups share a CU with the
+  // layout-exact 52 KB of LDS (SYRK64_LDS_EXACT = 1, the default since round 6): 5-7% faster than two in isolation
+  // (m = 20 000: k = 128 1 817 -> 1 693 us, k = 256 2 404 -> 2 286). The panel factorisation of the next panel runs
+  // beside this kernel, its workgroups need 107 KB of LDS and 256 VGPRs, and with three of these per CU a finished one
+  // leaves a hole they do not fit into: the update is therefore launched behind a gate that lets the factorisation
+  // become resident first (s1_gate, csrc/eigen_2stage.inc). Without the gate three per CU cost 13-42 ms at C3
+  // (profiles/r03/r03m_*, r06/r06b_gate_ab_C3.log: 0.4221 vs 0.4087 s); -DSYRK64_LDS_EXACT=0 builds two per CU.
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NJ = BN / 32;
   constexpr int CPT = 128 / BN;   // tile columns per 128-wide column pair

@@ -1,5 +1,5 @@
 set -x
-O=gpurun_out/${EVID:-r05z}; mkdir -p $O
+O=gpurun_out/${EVID:-r06z}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q --durations=12 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
@@ -43,6 +43,15 @@ if [ -n "$R04_EXTRAS" ]; then
   rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcB -o run -- $CMD > /dev/null 2>&1
   python tools/mfma_pmc.py $O/pmcA $O/pmcB $O/mfma_pmc_C3.json "$CMD" > $O/mfma_pmc_C3.log 2>&1
   rm -rf $O/pmcA $O/pmcB
+fi
+# ---- round 6: fabric traffic of the trailing update's launches INSIDE the fit (SYRK_PMC=1; two separate passes) ------
+if [ -n "$SYRK_PMC" ]; then
+  CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcF -o run -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcW -o run -- $CMD > /dev/null 2>&1
+  python tools/syrk_infit_pmc.py $O/pmcF $O/pmcW $O/syrk_infit_traffic_pmc.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- $CMD" > $O/syrk_infit_traffic_pmc.log 2>&1
+  rm -rf $O/pmcF $O/pmcW
+  cat $O/syrk_infit_traffic_pmc.log | tail -2
 fi
 if [ -n "$WITH_CPU" ]; then python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_C3_default_with_cpu_baseline.json; fi
 tail -3 $O/gpu_tests.log; cat $O/smoke.log | tail -2; cat $O/kernel_build_pmc.log; for f in $O/bench_*.json; do echo $f; python -c "

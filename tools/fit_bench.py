@@ -1,5 +1,5 @@
 """Time one bigKRLS() fit at an arbitrary config (development tool): python tools/fit_bench.py N P [Neig] [seed]"""
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 sys.path.insert(0, '.')
 import bigkrls_amd as bk
 from bigkrls_amd.synth import synth
@@ -7,7 +7,7 @@ n, p = int(sys.argv[1]), int(sys.argv[2])
 neig = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else None
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 104
 X, y = synth(n, p, seed)
-ctx = bk.Context(0)
+ctx = bk.Context(0, own_stream=bool(os.environ.get('BIGKRLS_S1_GRAPH') or os.environ.get('KNOB_AB_OWN_STREAM')))  # (a stream capture needs a stream of its own)
 for rep in range(2):
     T = {}
     t0 = time.perf_counter()

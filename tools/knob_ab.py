@@ -12,7 +12,7 @@ import bigkrls_amd as bk
 from bigkrls_amd.synth import synth
 n, p = int(sys.argv[1]), int(sys.argv[2])
 X, y = synth(n, p, 103)
-ctx = bk.Context(0)
+ctx = bk.Context(0, own_stream=bool(os.environ.get('BIGKRLS_S1_GRAPH') or os.environ.get('KNOB_AB_OWN_STREAM')))  # (a stream capture needs a stream of its own)
 best = 1e9; lam = None
 for rep in range(4):
     T = {}

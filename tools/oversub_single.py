@@ -41,7 +41,9 @@ def worker():
         out = bk.bigKRLS(y, X, ctx=ctx, noisy=False, **kw)
         lam.append((out["lambda"], out["lastkeeper"], float(out["coeffs"][0])))
     ok = all(v == lam[0] for v in lam)
-    print(f"n={n} p={p}: {reps} fits, lambda/lastkeeper/c[0] {'identical' if ok else 'DIFFER: ' + repr(lam)}", flush=True)
+    # (the context's recovery counters tell a replay after a fired watchdog -- launch-per-step kernels, last-digit
+    #  differences that eigtrunc = 0 amplifies into another kept-pair count, quirk Q7 -- from a silent fault)
+    print(f"n={n} p={p}: {reps} fits, lambda/lastkeeper/c[0] {'identical' if ok else 'DIFFER: ' + repr(lam)} counters {ctx.counters()}", flush=True)
     sys.exit(0 if ok else 1)
 
 

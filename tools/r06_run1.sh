@@ -17,8 +17,8 @@ BIGKRLS_VERBOSE=1 python tools/fit_bench.py 20000 20 > $O/verbose_C3.log 2>&1
 grep -E "d&c|divide|stage" $O/verbose_C3.log | tail -22
 BIGKRLS_VERBOSE=1 BIGKRLS_S1_GRAPH=1 timeout 300 python tools/fit_bench.py 5000 10 > $O/graph_verbose_C2.log 2>&1; grep -E "graph|stage 1|rep" $O/graph_verbose_C2.log | tail -8
 BIGKRLS_VERBOSE=1 BIGKRLS_S1_GRAPH=1 timeout 300 python tools/fit_bench.py 20000 20 > $O/graph_verbose_C3.log 2>&1; grep -E "graph|stage 1|rep" $O/graph_verbose_C3.log | tail -8
-timeout 600 python tools/knob_ab.py 5000 10 BIGKRLS_S1_GRAPH=2 - > $O/graph_ab_C2.log 2>&1; cat $O/graph_ab_C2.log | grep best
-timeout 600 python tools/knob_ab.py 20000 20 BIGKRLS_S1_GRAPH=2 - > $O/graph_ab_C3.log 2>&1; cat $O/graph_ab_C3.log | grep best
+KNOB_AB_OWN_STREAM=1 timeout 600 python tools/knob_ab.py 5000 10 BIGKRLS_S1_GRAPH=2 - > $O/graph_ab_C2.log 2>&1; cat $O/graph_ab_C2.log | grep best
+KNOB_AB_OWN_STREAM=1 timeout 600 python tools/knob_ab.py 20000 20 BIGKRLS_S1_GRAPH=2 - > $O/graph_ab_C3.log 2>&1; cat $O/graph_ab_C3.log | grep best
 # the trailing update at three workgroups per CU (-DSYRK64_LDS_EXACT=1) behind a gate that lets the panel factorisation's
 # workgroups become resident first (-DBK_S1_GATE): head / gate at two per CU / gate at three / three without the gate
 timeout 900 python tools/fit_ab.py 20000 20 bigkrls_amd/libbigkrls_hip.so tools/_ab/libbigkrls_gate2.so tools/_ab/libbigkrls_gate3.so tools/_ab/libbigkrls_exact3.so > $O/gate_ab_C3.log 2>&1; grep best $O/gate_ab_C3.log
@@ -27,3 +27,7 @@ timeout 600 python tools/fit_ab.py 5000 10 bigkrls_amd/libbigkrls_hip.so tools/_
 # change / as before (V'V chain, two stream changes)
 timeout 600 python tools/knob_ab.py 5000 10 - BIGKRLS_S1_SWAP_M=0 BIGKRLS_S1_TPQ=0,BIGKRLS_S1_SWAP_M=0 > $O/tpq_ab_C2.log 2>&1; grep best $O/tpq_ab_C2.log
 timeout 900 python tools/knob_ab.py 20000 20 - BIGKRLS_S1_SWAP_M=0 BIGKRLS_S1_TPQ=0,BIGKRLS_S1_SWAP_M=0 > $O/tpq_ab_C3.log 2>&1; grep best $O/tpq_ab_C3.log
+# one C2 panel step kernel by kernel with the T factor from pq_chol and the chain on one stream (compare profiles/r05/r05b_C2_panel_chain_timeline.log)
+rocprofv3 --kernel-trace --output-format csv -d $O/kt_C2 -o run -- python3 tools/eig_once.py 5000 10 > /dev/null 2>&1
+python tools/panel_chain_timeline.py $O/kt_C2 > $O/C2_panel_chain_timeline.log 2>&1; head -30 $O/C2_panel_chain_timeline.log | cut -c1-150
+f=$(find $O/kt_C2 -name "*kernel_trace.csv" | head -1); rm -rf $O/kt_C2
