@@ -380,6 +380,8 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
   if (ctx->ev_pq) (void)hipEventDestroy(ctx->ev_pq);
+  if (ctx->ev_graph) (void)hipEventDestroy(ctx->ev_graph);
+  if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return BIGKRLS_OK;

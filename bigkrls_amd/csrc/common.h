@@ -88,10 +88,12 @@ struct bigkrls_ctx {
   // device-side predicate of the next gemm() launches (kernel and split-K reduction return at once while *gemm_run_if
   // == 0): the T-factor chain of a stage-1 panel only runs when pq_chol left the panel to the Householder kernel
   const int* gemm_run_if = nullptr;
-  // BIGKRLS_S1_GRAPH (experiment, csrc/eigen.hip): the stage-1 panel loop of the last size, captured as a hipGraph; valid
+  // the stage-1 panel loop of the last size, captured as a hipGraph (stage1_run, csrc/eigen.hip); valid
   // while the workspace it points into has not been reallocated (ws_generation)
   void* s1_graph_exec = nullptr;
-  int s1_graph_n = 0, s1_graph_warm_n = 0;
+  int s1_graph_n = 0, s1_graph_warm_n = 0, s1_graph_seen = 0;
+  hipStream_t graph_stream = nullptr;   // (contexts on the default stream: where the graph is captured and replayed)
+  hipEvent_t ev_graph = nullptr;
   int64_t s1_graph_gen = -1, ws_generation = 0;
   const void* s1_graph_W = nullptr;
 };

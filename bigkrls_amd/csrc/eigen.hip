@@ -1135,6 +1135,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
   A.pole_of_row = a_int; A.srccol = a_int + n; A.cpos = a_int + 2 * n; A.defsrc = a_int + 3 * n; A.defdst = a_int + 4 * n;
   std::memset(A.dlam, 0, (size_t)2 * n * sizeof(double));
   std::memset(a_int, 0, (size_t)5 * n * sizeof(int));
+  A.rowpos.resize(n);
   // Few eigenvectors wanted (truncation or Neig << N): the merge operators of the top LAZY_TOP
   // levels below the root stay factored. Q of depth Dl+1 is the last one formed; above it only the
   // first and last row of every node's eigenvector matrix (what the parent's z needs) are
@@ -2432,40 +2433,63 @@ struct DistS1 {
   int agg_mode = 0;             // panels per trailing update the ranks agreed on: 4 (groups of four, then pairs), 2 (pairs), 0 (none)
 };
 
-// BIGKRLS_S1_GRAPH (experiment; off by default): the stage-1 panel loop as a captured hipGraph. The loop has no host
-// synchronisation and no host decision that depends on device data -- every launch dimension follows from n -- and its two
-// streams meet only through ev_fork / ev_join / ev_join2, the fork-join shape stream capture accepts. The first
-// decomposition of a size on a context runs uncaptured (workspace growth, hipFuncSetAttribute and the side stream's
-// creation must not happen inside a capture); from the second on the loop is captured once, instantiated, and the
-// executable graph replayed for as long as the workspace it points into has not moved (ctx->ws_generation).
-//   =1: capture + instantiate + launch at every call, the three timed (BIGKRLS_VERBOSE)   =2: cached executable graph
+// The stage-1 panel loop as a captured hipGraph (round 6). The loop has no host synchronisation and no host decision
+// that depends on device data -- every launch dimension follows from n -- and its two streams meet only through
+// ev_fork / ev_join / ev_join2 / ev_pq, the fork-join shape stream capture accepts. Replayed as an executable graph the
+// ~3 800 launches of an N = 20 000 decomposition cost 11 ms of host time instead of being issued one by one and the fit
+// is 3-6 ms faster (same box, fresh processes: profiles/r06/r06b_stage1_graph_ab_C3.log); at N = 5 000 there is nothing
+// to gain (r06b_stage1_graph_ab_C2.log). Capture + instantiation cost 5 + 16 ms at N = 20 000, so:
+//   * the first TWO decompositions of a size on a context run the plain loop (workspace growth, hipFuncSetAttribute and
+//     the side stream's creation must not happen inside a capture anyway), the third captures, instantiates and
+//     replays, later ones replay for as long as the workspace the graph points into has not moved
+//     (ctx->ws_generation) -- repeated fits of one size (cross-validation folds, refits, a benchmark loop) gain, a
+//     single fit is never slowed down;
+//   * only for n >= S1_GRAPH_MIN_N, never while profiling / tracing / after a watchdog.
+// A context on the process's default stream (which cannot be captured) captures on, and replays through, a stream of
+// the context's own, ordered against the default stream by two events.
+//   BIGKRLS_S1_GRAPH=0: never   =1: capture + instantiate + launch at every call from the second on, timed
+//   (BIGKRLS_VERBOSE)   =2: cached from the second call on, any n
+constexpr int S1_GRAPH_MIN_N = 8192;
 static int stage1_run(bigkrls_ctx* ctx, double* W, int n, double* taus1, const Stage1Ws& s1) {
-  static const int gmode = [] { const char* e = getenv("BIGKRLS_S1_GRAPH"); return e ? atoi(e) : 0; }();
-  // (the process's default stream cannot be captured: contexts on it keep the plain loop)
-  if (gmode <= 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main || ctx->stream == nullptr)
+  static const int gmode = [] { const char* e = getenv("BIGKRLS_S1_GRAPH"); return e ? atoi(e) : -1; }();
+  if (gmode == 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main || (gmode < 0 && n < S1_GRAPH_MIN_N))
     return stage1_to_band(ctx, W, n, taus1, s1);
   if (ctx->s1_graph_warm_n != n) {
     ctx->s1_graph_warm_n = n;
+    ctx->s1_graph_seen = 0;
+  }
+  if (ctx->s1_graph_seen < (gmode < 0 ? 2 : 1)) {
+    ctx->s1_graph_seen++;
     return stage1_to_band(ctx, W, n, taus1, s1);
   }
-  hipStream_t st = ctx->stream;
+  hipStream_t user = ctx->stream, st = user;
+  if (user == nullptr) {             // the default stream cannot be captured
+    if (!ctx->graph_stream) {
+      BK_HIP(hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking));
+      BK_HIP(hipEventCreateWithFlags(&ctx->ev_graph, hipEventDisableTiming));
+    }
+    st = ctx->graph_stream;
+  }
   const bool verbose = getenv("BIGKRLS_VERBOSE") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
   };
-  const bool hit = gmode >= 2 && ctx->s1_graph_exec && ctx->s1_graph_n == n && ctx->s1_graph_gen == ctx->ws_generation &&
+  const bool hit = gmode != 1 && ctx->s1_graph_exec && ctx->s1_graph_n == n && ctx->s1_graph_gen == ctx->ws_generation &&
                    ctx->s1_graph_W == (const void*)W;
   const auto t0 = now();
   if (!hit) {
     if (ctx->s1_graph_exec) {
-      BK_HIP(hipStreamSynchronize(st));
+      BK_HIP(hipStreamSynchronize(user));
+      if (st != user) BK_HIP(hipStreamSynchronize(st));
       (void)hipGraphExecDestroy((hipGraphExec_t)ctx->s1_graph_exec);
       ctx->s1_graph_exec = nullptr;
     }
     hipGraph_t graph = nullptr;
     BK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    ctx->stream = st;
     const int rc = stage1_to_band(ctx, W, n, taus1, s1);
+    ctx->stream = user;
     const hipError_t ec = hipStreamEndCapture(st, &graph);      // (always: the stream must leave capture mode)
     if (rc != BIGKRLS_OK) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -2494,10 +2518,18 @@ static int stage1_run(bigkrls_ctx* ctx, double* W, int n, double* taus1, const S
               ms(t1, now()));
   }
   const auto t2 = now();
+  if (st != user) {                  // everything queued on the default stream so far comes first ...
+    BK_HIP(hipEventRecord(ctx->ev_graph, user));
+    BK_HIP(hipStreamWaitEvent(st, ctx->ev_graph, 0));
+  }
   BK_HIP(hipGraphLaunch((hipGraphExec_t)ctx->s1_graph_exec, st));
+  if (st != user) {                  // ... and what follows on it waits for the graph
+    BK_HIP(hipEventRecord(ctx->ev_graph, st));
+    BK_HIP(hipStreamWaitEvent(user, ctx->ev_graph, 0));
+  }
   if (verbose) {
     const auto t3 = now();
-    BK_HIP(hipStreamSynchronize(st));
+    BK_HIP(hipStreamSynchronize(user));
     fprintf(stderr, "[bigkrls]   stage 1 as a graph: launch call %.2f ms, launch to completion %.2f ms%s\n", ms(t2, t3),
             ms(t2, now()), hit ? " (cached executable graph)" : "");
   }

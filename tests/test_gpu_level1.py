@@ -309,6 +309,39 @@ def test_eigen_is_run_to_run_deterministic(eig_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_eigen_stage1_as_a_captured_graph_is_bitwise_the_plain_loop(own_stream):
+    """From the third decomposition of one size on a context (n >= 8 192) the stage-1 panel loop is replayed as a captured
+    hipGraph (csrc/eigen.hip, stage1_run): decompositions 1-2 run the plain loop, 3 captures + instantiates + replays, 4-5
+    replay the cached executable graph -- all five bit for bit the same, on a context of the default stream (captured on
+    a stream of the context's own) and on an own-stream context; a size in between (another n) drops the cached graph."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    ctx = bk.Context(0, own_stream=own_stream)
+    rng = np.random.default_rng(17)
+    n, p = 8448, 6
+    X = rng.standard_normal((n, p))
+    K = ops.bGaussKernel(ctx.from_numpy(X), float(p))
+    first = ops.bEigen(K, n, 0.001)
+    v0, q0 = first.values.copy(), first.vectors.to_numpy()
+    assert abs(v0.sum() - n) < 1e-9 * n
+    for rep in range(4):
+        e = ops.bEigen(K, n, 0.001)
+        assert e.lastkeeper == first.lastkeeper, rep
+        assert np.array_equal(v0, e.values), rep
+        assert np.array_equal(q0, e.vectors.to_numpy()), rep
+    # another size in between, then the first one again (a fresh count: plain, plain, capture)
+    X2 = rng.standard_normal((8320, p))
+    K2 = ops.bGaussKernel(ctx.from_numpy(X2), float(p))
+    e2 = ops.bEigen(K2, 8320, 0.001)
+    assert abs(e2.values.sum() - 8320) < 1e-9 * 8320
+    for rep in range(3):
+        e = ops.bEigen(K, n, 0.001)
+        assert np.array_equal(v0, e.values), rep
+    assert ctx.counters() == {"redone": 0, "replayed": 0, "replica_diff": 0}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bc,pq", [("wavefront", "steps"), ("persistent", "steps"), ("resident", "resident"),
                                    ("lds", "resident")])
 @pytest.mark.parametrize("n", [513, 1283])
