@@ -522,6 +522,10 @@ struct MergeDesc {
   int k1, k2, k3, Kneed;
   int rot_off, nrot, ndef, rev;   // rev: columns stored in descending order of the roots (the root of the tree)
   double rho;
+  // where the merge's secular vectors go: column c at Ubase + uoff + c * uld -- the block (s, s) of the N x N buffer U
+  // (uoff = s + s N, uld = N), or, on a level whose operators stay factored, a contiguous K x K block of the stash
+  long long uoff;
+  int uld, pad_;
 };
 
 // Leaves of the divide & conquer tree (17..32 rows when n > 64): implicit QL with eigenvectors
@@ -662,114 +666,168 @@ __device__ __forceinline__ double rcp_fast(double x) {
 // from: delta_ij = dlam_i - lambda_j is evaluated where it is needed as (dlam_i - dorg_j) - tau_j, the form that
 // keeps its relative accuracy (LAPACK dlaed4's delta), instead of being stored as a K x K matrix -- at the root of an
 // N = 20 000 decomposition that matrix was 1.7 GB written row-scattered here and read column-strided by dc_zhat.
+// R roots per wave (round 6): every evaluation of the secular function streams the K poles and weights -- 232 KB per
+// root and evaluation at the root of an N = 20 000 tree, ~100 000 evaluations: the kernel was bound by L2 bandwidth, not
+// by its reciprocals. A wave now carries DC_SEC_R neighbouring roots through their iterations together: dl_i and w_i^2
+// are loaded once per pole for all of them. Per root the arithmetic, the order of the sums and the iteration are exactly
+// those of one root per wave (bitwise the same roots); a root that has converged simply stops updating its state while
+// its neighbours finish.
+constexpr int DC_SEC_R = 4;
 __global__ __launch_bounds__(256) void dc_secular(const MergeDesc* __restrict__ descs,
                                                   const double* __restrict__ dlam,
                                                   const double* __restrict__ w,
                                                   double* __restrict__ lam, double* __restrict__ dorg_out,
                                                   double* __restrict__ tau_out) {
+  constexpr int R = DC_SEC_R;
   const MergeDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   const int K = d.K;
-  if (j >= K) return;
+  if (j0 >= K) return;
   const int base = d.s;
   const double* dl = dlam + base;
   const double* ww = w + base;
   const double rho = d.rho;
-  int org;
-  double sgn, lo, hi;
-  if (j < K - 1) {
-    const double dj = dl[j], dj1 = dl[j + 1];
-    const double half = 0.5 * (dj1 - dj);
-    // value at the midpoint, split into the poles below and above ((dj1 - dl_i) - half = -((dl_i - dj) - half): one
-    // reciprocal per term serves all three sums)
-    double rl = 0.0, rr = 0.0;
-    for (int i = lane; i < K; i += 64) {
-      const double t = ww[i] * ww[i] * rcp_fast((dl[i] - dj) - half);
-      if (i > j) rr += t;
-      else rl -= t;
+  int org[R];
+  double sgn[R], lo[R], hi[R], dorg[R], pa[R], pb[R], x[R];
+  bool live[R], two_poles[R];
+  // ---- brackets: the value at the midpoint of the root's interval (all but the last root), one pass over the poles -----
+  {
+    double dj[R], half[R], rl[R], rr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = j0 + r;
+      live[r] = j < K;
+      const int jc = live[r] ? j : K - 1;                 // (a slot past the end repeats the last root and is never stored)
+      dj[r] = dl[jc];
+      half[r] = (jc < K - 1) ? 0.5 * (dl[jc + 1] - dj[r]) : 0.0;
+      rl[r] = 0.0; rr[r] = 0.0;
     }
-    rr = wsum(rr);
-    rl = wsum(rl);
-    const double g = 1.0 + rho * (rr - rl);
-    hi = half;
-    if (g >= 0.0) {
-      org = j; sgn = 1.0;
-      const double R = 1.0 + rho * rr;
-      lo = rho * ww[j] * ww[j] / R;
-    } else {
-      org = j + 1; sgn = -1.0;
-      const double R = -1.0 + rho * rl;
-      lo = (R > 0.0) ? rho * ww[j + 1] * ww[j + 1] / R : 0.0;
-    }
-  } else {
-    org = j; sgn = 1.0;
     double s2 = 0.0;
-    for (int i = lane; i < K; i += 64) s2 += ww[i] * ww[i];
+    for (int i = lane; i < K; i += 64) {
+      const double wi = ww[i], w2 = wi * wi, di = dl[i];
+      s2 += w2;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int jc = min(j0 + r, K - 1);
+        if (jc < K - 1) {                                  // (uniform per r)
+          const double t = w2 * rcp_fast((di - dj[r]) - half[r]);
+          if (i > jc) rr[r] += t;
+          else rl[r] -= t;
+        }
+      }
+    }
     s2 = wsum(s2);
-    hi = rho * s2 * (1.0 + 8.0 * DEPS);
-    lo = rho * ww[j] * ww[j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int jc = min(j0 + r, K - 1);
+      if (jc < K - 1) {
+        const double srr = wsum(rr[r]), srl = wsum(rl[r]);
+        const double g = 1.0 + rho * (srr - srl);
+        hi[r] = half[r];
+        if (g >= 0.0) {
+          org[r] = jc; sgn[r] = 1.0;
+          const double Rr = 1.0 + rho * srr;
+          lo[r] = rho * ww[jc] * ww[jc] / Rr;
+        } else {
+          org[r] = jc + 1; sgn[r] = -1.0;
+          const double Rr = -1.0 + rho * srl;
+          lo[r] = (Rr > 0.0) ? rho * ww[jc + 1] * ww[jc + 1] / Rr : 0.0;
+        }
+      } else {
+        org[r] = jc; sgn[r] = 1.0;
+        hi[r] = rho * s2 * (1.0 + 8.0 * DEPS);
+        lo[r] = rho * ww[jc] * ww[jc];
+      }
+      lo[r] = fmin(lo[r], hi[r]) * (1.0 - 8.0 * DEPS);
+      if (!(lo[r] > 0.0)) lo[r] = hi[r] * 1e-300;
+      dorg[r] = dl[org[r]];
+      // the two poles next to the root, measured from the origin (one of them is 0); the last root has no upper pole
+      two_poles[r] = jc < K - 1;
+      pa[r] = two_poles[r] ? dl[jc] - dorg[r] : 0.0;
+      pb[r] = two_poles[r] ? dl[jc + 1] - dorg[r] : 0.0;
+      x[r] = (hi[r] > 4.0 * lo[r]) ? sqrt(lo[r]) * sqrt(hi[r]) : 0.5 * (lo[r] + hi[r]);
+    }
   }
-  lo = fmin(lo, hi) * (1.0 - 8.0 * DEPS);
-  if (!(lo > 0.0)) lo = hi * 1e-300;
-  const double dorg = dl[org];
-  // the two poles next to the root, measured from the origin (one of them is 0); the last root has no upper pole
-  const bool two_poles = j < K - 1;
-  const double pa = two_poles ? dl[j] - dorg : 0.0, pb = two_poles ? dl[j + 1] - dorg : 0.0;
   // Safeguarded Newton inside the bracket [lo, hi] (in |tau|): every evaluation yields f, f' and
   // the sum of absolute terms (the rounding-error scale of f); the bracket is updated from the
   // sign of f, the Newton step is taken when it stays strictly inside the bracket and otherwise
   // the (geometric) midpoint. Stops when |f| is at the rounding level of its own evaluation
   // (LAPACK dlaed4's criterion) or the bracket has collapsed; the bisection alone needed ~60-100
   // evaluations per root, this needs ~6-12.
-  double x = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
+  bool run[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) run[r] = live[r];
   for (int it = 0; it < 200; ++it) {
-    if (!(hi > lo) || !(x > lo) || !(x < hi)) break;
-    const double tau = sgn * x;
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (run[r] && (!(hi[r] > lo[r]) || !(x[r] > lo[r]) || !(x[r] < hi[r]))) run[r] = false;
+      any = any || run[r];
+    }
+    if (!any) break;                                       // uniform (every lane holds the same scalars)
+    double tau[R], psi[R], phi[R], dpsi[R], dphi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { tau[r] = sgn[r] * x[r]; psi[r] = phi[r] = dpsi[r] = dphi[r] = 0.0; }
     // psi: the poles up to j (terms < 0), phi: the poles above (terms > 0); derivatives likewise
-    double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
     for (int i = lane; i < K; i += 64) {
-      const double inv = rcp_fast((dl[i] - dorg) - tau);
-      const double t = ww[i] * ww[i] * inv;
-      if (i > j) { phi += t; dphi += t * inv; }
-      else       { psi += t; dpsi += t * inv; }
-    }
-    psi = wsum(psi); phi = wsum(phi); dpsi = rho * wsum(dpsi); dphi = rho * wsum(dphi);
-    const double g = 1.0 + rho * (psi + phi);
-    const double gp = dpsi + dphi;                      // df/dtau > 0
-    const double ga = 1.0 + rho * (phi - psi);          // sum of the absolute terms
-    const bool pos = (g >= 0.0);
-    if (sgn > 0.0) { if (pos) hi = x; else lo = x; }
-    else           { if (pos) lo = x; else hi = x; }
-    if (fabs(g) <= 8.0 * DEPS * ga) { lo = x; hi = x; break; }
-    // Step: psi and phi are each replaced by s + a / (pole - tau) through the nearest pole below / above with the
-    // value and slope they have here (the "middle way" of Li 1994, the scheme of LAPACK's dlaed4): the resulting
-    // quadratic in the increment eta is solved in the form that does not cancel. A plain Newton step in tau where
-    // that is not available (last root) or leaves the bracket; the (geometric) midpoint when Newton leaves it too.
-    double xn = sgn * (tau - g / gp);
-    if (two_poles) {
-      const double DA = pa - tau, DB = pb - tau;         // < 0 < (inside the interval)
-      const double c = g - DA * dpsi - DB * dphi;
-      const double a = (DA + DB) * g - DA * DB * gp;
-      const double b = DA * DB * g;
-      double eta;
-      if (c == 0.0) {
-        eta = b / a;
-      } else {
-        const double disc = sqrt(fabs(a * a - 4.0 * b * c));
-        eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+      const double wi = ww[i], w2 = wi * wi, di = dl[i];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (run[r]) {                                      // (uniform per r)
+          const double inv = rcp_fast((di - dorg[r]) - tau[r]);
+          const double t = w2 * inv;
+          if (i > j0 + r) { phi[r] += t; dphi[r] += t * inv; }
+          else            { psi[r] += t; dpsi[r] += t * inv; }
+        }
       }
-      const double xr = sgn * (tau + eta);
-      if (g * eta < 0.0 && xr > lo && xr < hi) xn = xr;  // (f increases: the step must go against the sign of f)
     }
-    const double mid = (hi > 4.0 * lo) ? sqrt(lo) * sqrt(hi) : 0.5 * (lo + hi);
-    x = (xn > lo && xn < hi) ? xn : mid;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!run[r]) continue;
+      const double spsi = wsum(psi[r]), sphi = wsum(phi[r]);
+      const double sdpsi = rho * wsum(dpsi[r]), sdphi = rho * wsum(dphi[r]);
+      const double g = 1.0 + rho * (spsi + sphi);
+      const double gp = sdpsi + sdphi;                     // df/dtau > 0
+      const double ga = 1.0 + rho * (sphi - spsi);         // sum of the absolute terms
+      const bool pos = (g >= 0.0);
+      if (sgn[r] > 0.0) { if (pos) hi[r] = x[r]; else lo[r] = x[r]; }
+      else              { if (pos) lo[r] = x[r]; else hi[r] = x[r]; }
+      if (fabs(g) <= 8.0 * DEPS * ga) { lo[r] = x[r]; hi[r] = x[r]; run[r] = false; continue; }
+      // Step: psi and phi are each replaced by s + a / (pole - tau) through the nearest pole below / above with the
+      // value and slope they have here (the "middle way" of Li 1994, the scheme of LAPACK's dlaed4): the resulting
+      // quadratic in the increment eta is solved in the form that does not cancel. A plain Newton step in tau where
+      // that is not available (last root) or leaves the bracket; the (geometric) midpoint when Newton leaves it too.
+      double xn = sgn[r] * (tau[r] - g / gp);
+      if (two_poles[r]) {
+        const double DA = pa[r] - tau[r], DB = pb[r] - tau[r];   // < 0 < (inside the interval)
+        const double c = g - DA * sdpsi - DB * sdphi;
+        const double a = (DA + DB) * g - DA * DB * gp;
+        const double b = DA * DB * g;
+        double eta;
+        if (c == 0.0) {
+          eta = b / a;
+        } else {
+          const double disc = sqrt(fabs(a * a - 4.0 * b * c));
+          eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+        }
+        const double xr = sgn[r] * (tau[r] + eta);
+        if (g * eta < 0.0 && xr > lo[r] && xr < hi[r]) xn = xr;  // (f increases: the step must go against the sign of f)
+      }
+      const double mid = (hi[r] > 4.0 * lo[r]) ? sqrt(lo[r]) * sqrt(hi[r]) : 0.5 * (lo[r] + hi[r]);
+      x[r] = (xn > lo[r] && xn < hi[r]) ? xn : mid;
+    }
   }
-  const double tau = sgn * 0.5 * (lo + hi);
   if (lane == 0) {
-    lam[base + j] = dorg + tau;
-    dorg_out[base + j] = dorg;
-    tau_out[base + j] = tau;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (live[r]) {
+        const double tau = sgn[r] * 0.5 * (lo[r] + hi[r]);
+        lam[base + j0 + r] = dorg[r] + tau;
+        dorg_out[base + j0 + r] = dorg[r];
+        tau_out[base + j0 + r] = tau;
+      }
+    }
   }
 }
 
@@ -805,7 +863,7 @@ __global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ 
                                                   const double* __restrict__ dlam,
                                                   const int* __restrict__ pole_of_row,
                                                   const double* __restrict__ dorg, const double* __restrict__ tau,
-                                                  double* __restrict__ U, int64_t ld) {
+                                                  double* __restrict__ U) {
   __shared__ double sh[4];
   const MergeDesc d = descs[blockIdx.y];
   const int cp = blockIdx.x;
@@ -813,7 +871,7 @@ __global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ 
   const int base = d.s;
   const int j = d.rev ? d.K - 1 - cp : cp;
   const double dj = dorg[base + j], tj = tau[base + j];
-  double* u = U + base + (int64_t)(base + cp) * ld;
+  double* u = U + d.uoff + (int64_t)cp * d.uld;
   const double* zh = zhat + base;
   double ss = 0.0;
   for (int r = threadIdx.x; r < d.K; r += 256) {
@@ -857,13 +915,13 @@ __global__ void dc_gather_rows(const MergeDesc* __restrict__ descs, const double
 __global__ __launch_bounds__(256) void dc_rows_times_u(const MergeDesc* __restrict__ descs,
                                                        const double* __restrict__ gf,
                                                        const double* __restrict__ gl,
-                                                       const double* __restrict__ U, int64_t ld,
+                                                       const double* __restrict__ U,
                                                        double* __restrict__ of, double* __restrict__ ol) {
   __shared__ double sh[4];
   const MergeDesc d = descs[blockIdx.y];
   const int j = blockIdx.x;
   if (j >= d.K) return;
-  const double* u = U + d.s + (int64_t)(d.s + j) * ld;
+  const double* u = U + d.uoff + (int64_t)j * d.uld;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < d.K; i += 256) {
     const double v = u[i];
@@ -984,9 +1042,9 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
   const double rho = 2.0 * std::fabs(ecut);
   // scratch reused across the merges of a level (thousands of small merges at the bottom of the tree)
   static thread_local std::vector<double> z, D;
-  static thread_local std::vector<std::pair<double, int>> keyed;
+  static thread_local std::vector<std::pair<double, int>> keyed, kbuf;
   static thread_local std::vector<int> order, typ, nd, df;
-  z.resize(m); D.resize(m); keyed.resize(m); order.resize(m); typ.resize(m);
+  z.resize(m); D.resize(m); keyed.resize(m); kbuf.resize(m); order.resize(m); typ.resize(m);
   nd.clear(); df.clear();
   const double isq2 = 1.0 / std::sqrt(2.0);
   double dmax = 0.0, zmax = 0.0;
@@ -1007,9 +1065,11 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
     if (!std::is_sorted(keyed.begin() + n1, keyed.begin() + n1 + kr)) kr = 0;
     std::sort(keyed.begin() + kl, keyed.begin() + n1);
     std::sort(keyed.begin() + n1 + kr, keyed.end());
-    std::inplace_merge(keyed.begin(), keyed.begin() + kl, keyed.begin() + n1);
-    std::inplace_merge(keyed.begin() + n1, keyed.begin() + n1 + kr, keyed.end());
-    std::inplace_merge(keyed.begin(), keyed.begin() + n1, keyed.end());
+    // (std::merge into the scratch list and back: std::inplace_merge allocates its buffer at every call -- three calls
+    //  per merge, thousands of merges per level)
+    std::merge(keyed.begin(), keyed.begin() + kl, keyed.begin() + kl, keyed.begin() + n1, kbuf.begin());
+    std::merge(keyed.begin() + n1, keyed.begin() + n1 + kr, keyed.begin() + n1 + kr, keyed.end(), kbuf.begin() + n1);
+    std::merge(kbuf.begin(), kbuf.begin() + n1, kbuf.begin() + n1, kbuf.end(), keyed.begin());
   }
   for (int t = 0; t < m; ++t) order[t] = keyed[t].second;
   const double tol = 8.0 * DEPS * std::max(dmax, zmax);
@@ -1023,10 +1083,18 @@ void host_merge(const Node& L, const Node& R, double ecut, const double* zraw, M
       if (rho * std::fabs(z[t]) <= tol) { df.push_back(t); typ[t] = 4; continue; }
       if (pj < 0) { pj = t; continue; }
       double sv = z[pj], cv = z[t];
-      const double tau = std::hypot(cv, sv);
       const double tt = D[t] - D[pj];
-      cv /= tau; sv = -sv / tau;
-      if (std::fabs(tt * cv * sv) <= tol) {
+      // dlaed2's test |tt c s| <= tol with c = z_t / tau, s = -z_pj / tau, tau = hypot(z_t, z_pj), in the form that
+      // needs neither the root nor the divisions (z is normalised: no overflow): they are only formed for the rare pair
+      // that deflates -- the scan visits every non-deflated entry of every level, and hypot + two divisions per entry
+      // were most of its time
+      const double ss = cv * cv + sv * sv;
+      const double tau_safe = (ss > 1e-280) ? 0.0 : std::hypot(cv, sv);     // (squares that underflow: the safe form)
+      const bool defl = (ss > 1e-280) ? (std::fabs(tt * cv * sv) <= tol * ss)
+                                      : (std::fabs(tt * (cv / tau_safe) * (sv / tau_safe)) <= tol);
+      if (defl) {
+        const double tau = (ss > 1e-280) ? std::sqrt(ss) : tau_safe;
+        cv /= tau; sv = -sv / tau;
         z[t] = tau; z[pj] = 0.0;
         if (typ[t] != typ[pj]) typ[t] = 2;
         typ[pj] = 4;
@@ -1334,6 +1402,24 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
       max_ndef = std::max(max_ndef, descs[q].ndef);
     }
     const bool is_root = (depth == 0);
+    // where this level's secular vectors are written: straight into the stash on a factored level below the root (their
+    // K x K blocks used to be formed in U and copied: 1.9 GB of copies at N = 20 000), else block (s, s) of U
+    const bool u_to_stash = lazy_level && !is_root;
+    if (u_to_stash && stash == nullptr) stash = Qn;
+    std::vector<int64_t> level_stash_off(u_to_stash ? nm : 0);
+    for (int q = 0; q < nm; ++q) {
+      MergeDesc& md = descs[q];
+      if (u_to_stash) {
+        level_stash_off[q] = stash_used;
+        md.uoff = stash_used;
+        md.uld = std::max(md.K, 1);
+        stash_used += (int64_t)md.K * md.K;
+      } else {
+        md.uoff = md.s + (int64_t)md.s * N;
+        md.uld = n;
+      }
+    }
+    double* Ubase = u_to_stash ? stash : U;
     if (is_root) {
       // store roots in descending order so that the kept ones are a prefix
       const int K = descs[0].K, s = descs[0].s;
@@ -1380,7 +1466,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     if (maxK > 0) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
-        hipLaunchKernelGGL(dc_secular, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
+        hipLaunchKernelGGL(dc_secular, dim3((maxK + 4 * DC_SEC_R - 1) / (4 * DC_SEC_R), nb), dim3(256), 0, st,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_dlam,
                            (const double*)d_w, d_lam, d_dorg, d_tau);
         hipLaunchKernelGGL(dc_zhat, dim3((maxK + 3) / 4, nb), dim3(256), 0, st,
@@ -1475,7 +1561,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         const int nb = std::min(65535, nm - b0);
         hipLaunchKernelGGL(dc_vectors, dim3(maxKneed, nb), dim3(256), 0, st,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, (const double*)d_dlam,
-                           (const int*)d_pole, (const double*)d_dorg, (const double*)d_tau, U, N);
+                           (const int*)d_pole, (const double*)d_dorg, (const double*)d_tau, Ubase);
       }
       BK_CHECK_LAUNCH();
     }
@@ -1491,19 +1577,12 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         for (auto& md : L.descs) md.nrot = 0;
       }
       if (!is_root) {
-        // stash the secular-vector blocks (the U buffer is reused by the next level) in the idle
-        // ping-pong copy of Q, and push the boundary rows through the merge
-        if (stash == nullptr) stash = Qn;
-        L.stash_off.resize(nm);
+        // the secular-vector blocks were written straight into the stash (the idle ping-pong copy of Q: the U buffer is
+        // reused by the next level); push the boundary rows through the merge
+        L.stash_off = level_stash_off;
         std::vector<double> gfh(n, 0.0), glh(n, 0.0);
         for (int q = 0; q < nm; ++q) {
           const MergeDesc& md = descs[q];
-          L.stash_off[q] = stash_used;
-          if (md.K > 0)
-            BK_HIP(hipMemcpy2DAsync(stash + stash_used, (size_t)md.K * sizeof(double),
-                                    U + md.s + (int64_t)md.s * N, (size_t)N * sizeof(double),
-                                    (size_t)md.K * sizeof(double), (size_t)md.K, hipMemcpyDeviceToDevice, st));
-          stash_used += (int64_t)md.K * md.K;
           for (int i = 0; i < md.K; ++i) {
             gfh[md.s + i] = yf[md.s + A.srccol[md.s + i]];
             glh[md.s + i] = yl[md.s + A.srccol[md.s + i]];
@@ -1516,7 +1595,7 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
             const int nb = std::min(65535, nm - b0);
             hipLaunchKernelGGL(dc_rows_times_u, dim3(maxK, nb), dim3(256), 0, st,
                                (const MergeDesc*)(d_descs + b0), (const double*)d_gf, (const double*)d_gl,
-                               (const double*)U, N, d_of, d_ol);
+                               (const double*)Ubase, d_of, d_ol);
           }
           BK_CHECK_LAUNCH();
         }
@@ -2433,25 +2512,27 @@ struct DistS1 {
   int agg_mode = 0;             // panels per trailing update the ranks agreed on: 4 (groups of four, then pairs), 2 (pairs), 0 (none)
 };
 
-// The stage-1 panel loop as a captured hipGraph (round 6). The loop has no host synchronisation and no host decision
-// that depends on device data -- every launch dimension follows from n -- and its two streams meet only through
-// ev_fork / ev_join / ev_join2 / ev_pq, the fork-join shape stream capture accepts. Replayed as an executable graph the
-// ~3 800 launches of an N = 20 000 decomposition cost 11 ms of host time instead of being issued one by one and the fit
-// is 3-6 ms faster (same box, fresh processes: profiles/r06/r06b_stage1_graph_ab_C3.log); at N = 5 000 there is nothing
-// to gain (r06b_stage1_graph_ab_C2.log). Capture + instantiation cost 5 + 16 ms at N = 20 000, so:
-//   * the first TWO decompositions of a size on a context run the plain loop (workspace growth, hipFuncSetAttribute and
-//     the side stream's creation must not happen inside a capture anyway), the third captures, instantiates and
-//     replays, later ones replay for as long as the workspace the graph points into has not moved
-//     (ctx->ws_generation) -- repeated fits of one size (cross-validation folds, refits, a benchmark loop) gain, a
-//     single fit is never slowed down;
-//   * only for n >= S1_GRAPH_MIN_N, never while profiling / tracing / after a watchdog.
-// A context on the process's default stream (which cannot be captured) captures on, and replays through, a stream of
-// the context's own, ordered against the default stream by two events.
-//   BIGKRLS_S1_GRAPH=0: never   =1: capture + instantiate + launch at every call from the second on, timed
-//   (BIGKRLS_VERBOSE)   =2: cached from the second call on, any n
+// The stage-1 panel loop as a captured hipGraph (round 6; OPT-IN, off by default). The loop has no host synchronisation
+// and no host decision that depends on device data -- every launch dimension follows from n -- and its two streams meet
+// only through ev_fork / ev_join / ev_join2 / ev_pq, the fork-join shape stream capture accepts: 824 nodes at N = 5 000,
+// 3 823 at N = 20 000 (capture 1 / 5 ms, instantiation 12 / 16 ms, the launch call 2.4 / 11 ms of host time). Measured,
+// same box, fresh processes: on contexts with a stream of their own the replayed graph was 3-6 ms faster at N = 20 000
+// and equal at N = 5 000 (profiles/r06/r06b_stage1_graph_ab_*.log, before the gate below existed); on the default
+// stream -- what bench.py and every Python-driven fit use -- and with the final kernels it is EQUAL OR SLOWER at
+// N = 10 000 / 14 000 / 20 000 (0.1183 vs 0.1181, 0.2018 vs 0.2012-0.2019, 0.4044-0.4050 vs 0.4039-0.4045 s:
+// r06c_stage1_graph_ab_*.log): the loop is not bound by launch overhead. Kept as an experiment switch, results bitwise
+// those of the plain loop (tests/test_gpu_level1.py).
+//   BIGKRLS_S1_GRAPH=-1: from the third decomposition of a size with n >= S1_GRAPH_MIN_N (the first two run the plain
+//   loop: workspace growth, hipFuncSetAttribute and the side stream's creation must not happen inside a capture), the
+//   executable graph cached for as long as the workspace it points into has not moved (ctx->ws_generation); =2: cached
+//   from the second call on, any n; =1: capture + instantiate + launch at every call from the second on, timed under
+//   BIGKRLS_VERBOSE. Never while profiling / tracing / after a watchdog. A context on the process's default stream
+//   (which cannot be captured) captures on, and replays through, a stream of the context's own, ordered against the
+//   default stream by two events.
 constexpr int S1_GRAPH_MIN_N = 8192;
 static int stage1_run(bigkrls_ctx* ctx, double* W, int n, double* taus1, const Stage1Ws& s1) {
-  static const int gmode = [] { const char* e = getenv("BIGKRLS_S1_GRAPH"); return e ? atoi(e) : -1; }();
+  const char* genv = getenv("BIGKRLS_S1_GRAPH");           // (per call: the tests switch it)
+  const int gmode = genv ? atoi(genv) : 0;
   if (gmode == 0 || ctx->profile || trace_on() || ctx->no_resident || ctx->side_is_main || (gmode < 0 && n < S1_GRAPH_MIN_N))
     return stage1_to_band(ctx, W, n, taus1, s1);
   if (ctx->s1_graph_warm_n != n) {

@@ -310,11 +310,13 @@ def test_eigen_is_run_to_run_deterministic(eig_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("own_stream", [False, True])
-def test_eigen_stage1_as_a_captured_graph_is_bitwise_the_plain_loop(own_stream):
-    """From the third decomposition of one size on a context (n >= 8 192) the stage-1 panel loop is replayed as a captured
-    hipGraph (csrc/eigen.hip, stage1_run): decompositions 1-2 run the plain loop, 3 captures + instantiates + replays, 4-5
-    replay the cached executable graph -- all five bit for bit the same, on a context of the default stream (captured on
-    a stream of the context's own) and on an own-stream context; a size in between (another n) drops the cached graph."""
+def test_eigen_stage1_as_a_captured_graph_is_bitwise_the_plain_loop(own_stream, monkeypatch):
+    """BIGKRLS_S1_GRAPH=-1 (an experiment switch, off by default): from the third decomposition of one size on a context
+    (n >= 8 192) the stage-1 panel loop is replayed as a captured hipGraph (csrc/eigen.hip, stage1_run): decompositions 1-2
+    run the plain loop, 3 captures + instantiates + replays, 4-5 replay the cached executable graph -- all five bit for bit
+    the same, on a context of the default stream (captured on a stream of the context's own) and on an own-stream
+    context; a size in between (another n) drops the cached graph."""
+    monkeypatch.setenv("BIGKRLS_S1_GRAPH", "-1")
     import bigkrls_amd as bk
     from bigkrls_amd import ops
     ctx = bk.Context(0, own_stream=own_stream)
