@@ -2850,15 +2850,6 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(side_stream_get(ctx));
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
-    if (bt1_grouped) {
-      // after the bulge chasing (its workgroups fill every CU's LDS; sharing the GPU only slows it
-      // down), i.e. concurrently with the host-bound divide & conquer
-      BK_HIP(hipEventRecord(ctx->ev_fork, st));
-      BK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
-                            ctx->side_stream));
-      BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
-    }
     int h_err = 0;
     PinnedFetch pf2(ctx, 1);
     BK_TRY(pf2.add(&h_err, bc_err, sizeof(int)));
@@ -2877,14 +2868,27 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // on the look-ahead stream: they are not needed before the divide & conquer has finished
       BK_TRY(side_stream_get(ctx));
       hipStream_t side = ctx->side_stream;
-      BK_HIP(hipEventRecord(ctx->ev_join2, st));         // the bulge chasing is done
-      BK_HIP(hipStreamWaitEvent(side, ctx->ev_join2, 0));
+      BK_HIP(hipEventRecord(ctx->ev_fork, st));          // the bulge chasing is done
+      BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
       BK_HIP(hipMemcpyAsync(bt2_dtoff, bt2_toff.data(), bt2_toff.size() * sizeof(int64_t), hipMemcpyHostToDevice, side));
       const int ngroups = (int)bt2_toff.size() - 1, ntmax = (n - 2) / S2_B + 1;
       hipLaunchKernelGGL(bt2_build_t, dim3(ntmax, ngroups), dim3(256), 0, side, n, (const int64_t*)d_soff,
                          (const double*)VV, (const double*)TT, (const int64_t*)bt2_dtoff, bt2_T);
       BK_CHECK_LAUNCH();
-      BK_HIP(hipEventRecord(ctx->ev_join, side));
+      BK_HIP(hipEventRecord(ctx->ev_join2, side));       // what the stage-2 back-transform waits for
+    }
+    if (bt1_grouped && h_err == 0) {
+      // The merged block reflectors of the stage-1 back-transform, on the look-ahead stream BEHIND the T factors above
+      // (round 6): after the bulge chasing (its workgroups fill every CU's LDS; sharing the GPU only slows it down),
+      // beside the divide & conquer -- and, since that takes 17 ms at N = 20 000 and these launches 20, beside the first
+      // milliseconds of the stage-2 back-transform, which no longer waits for them: only the stage-1 back-transform does.
+      BK_HIP(hipEventRecord(ctx->ev_fork, st));
+      BK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
+                            ctx->side_stream));
+      BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+    } else if (bt1_grouped) {
+      bt1_V = nullptr;               // (the decomposition is about to be redone)
     }
     if (h_err != 0 && mode == EIG_RESUME) {
       set_error("eigen: watchdog of the LDS-resident bulge chasing fired after the distributed stage 1");
@@ -2951,7 +2955,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int pnv = pc1 - pc0;
     if (pnv > 0 && two_stage) {
       tick("gather kept columns");
-      if (bt2_T != nullptr || bt1_V != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join2, 0));
       // (the watchdog word of the bulge chasing, read back as zero above, now serves the persistent back-transform)
       bt2_err = (bt2_T != nullptr) ? (int*)scratch : nullptr;
       BK_TRY(back_transform_stage2(ctx, n, d_soff, VV, TT, pvecs, ldv, pnv, bt2_dtoff, bt2_T,
@@ -2960,9 +2964,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       void* pw12 = nullptr;
       const int64_t bt1_w = (int64_t)bt1_grp_for(n) * S2_B;
       BK_TRY(ws_get(ctx, SLOT_EIG_Z, 2 * bt1_w * pnv * sizeof(double), &pw12));
-      if (bt1_V != nullptr)
+      if (bt1_V != nullptr) {
+        BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
         BK_TRY(back_transform_stage1_grouped(ctx, n, bt1, bt1_V, bt1_T, pvecs, ldv, pnv, (double*)pw12,
                                              (double*)pw12 + bt1_w * pnv));
+      }
       else
         BK_TRY(back_transform_stage1(ctx, W, n, taus1, pvecs, ldv, pnv, s1.Vp, s1.Tall, (double*)pw12,
                                      (double*)pw12 + (int64_t)S2_B * pnv));
@@ -2971,8 +2977,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(back_transform(ctx, W, n, tau, pvecs, ldv, pnv));
     }
   }
-  if (bt2_T != nullptr || bt1_V != nullptr)
-    BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));   // (also when no column was back-transformed)
+  // (also when no column was back-transformed: nothing of this call may still run on the look-ahead stream)
+  if (bt2_T != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join2, 0));
+  if (bt1_V != nullptr) BK_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
 #ifdef BK_FAULT_INJECT
   // BIGKRLS_FAULT=eig_garbage (test build): the FIRST decomposition after the variable is set comes back with its
   // middle kept eigenvector scaled by 1.001 -- a wrong result without any error, the kind the fit's verification

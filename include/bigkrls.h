@@ -41,6 +41,14 @@
  * partitioned decomposition is replayed once on every rank from a fresh copy of
  * its column block of K (csrc/fit.hip); BIGKRLS_EHIP (on every rank) only if the
  * replay fails too.
+ * Verification: bigkrls_fit / bigkrls_fit_dist check EVERY decomposition -- the dense
+ * path and the block Lanczos (Neig << N) alike -- against K itself before using it
+ * (trace when the whole spectrum is known; all kept pairs through two fixed +-1
+ * combinations: |K Q r - Q Lambda r| and | |Q r|^2 - k |; one pass over K) and redo
+ * it once; a second failure is BIGKRLS_EHIP. In a multi-GPU fit every rank then runs
+ * the lambda search on rank 0's eigenvalues (one broadcast of 8 Neig bytes): the
+ * ranks' branch sequences cannot diverge. bigkrls_ctx_get_counters() says how often
+ * a context took one of these paths.
  * Diagnostics: with BIGKRLS_TRACE_DIR=<dir> set, every process appends 64-bit hashes
  * of its collectives' inputs / outputs and of the fit's intermediate results to
  * <dir>/pid<pid>.trace (csrc/trace.hip; compared by tools/trace_diff.py). Off
