@@ -863,7 +863,14 @@ __global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ 
                                                   const double* __restrict__ dlam,
                                                   const int* __restrict__ pole_of_row,
                                                   const double* __restrict__ dorg, const double* __restrict__ tau,
-                                                  double* __restrict__ U) {
+                                                  double* __restrict__ U, const double* __restrict__ gf,
+                                                  const double* __restrict__ gl, double* __restrict__ of,
+                                                  double* __restrict__ ol) {
+  // Column cp of the merge's secular-vector matrix, normalised: the entries are formed twice (norm, then value) rather
+  // than stored, re-read and rescaled -- a division is cheaper than two more passes over K x K doubles (0.96 GB per pass
+  // at the level below the root of an N = 20 000 tree). With gf != nullptr (a level whose operators stay factored) the
+  // column's products with the gathered first / last rows of the children, of[j] = gf' u_j and ol[j] = gl' u_j, are
+  // taken from the same pass (they were a kernel of their own that read the block once more).
   __shared__ double sh[4];
   const MergeDesc d = descs[blockIdx.y];
   const int cp = blockIdx.x;
@@ -876,12 +883,25 @@ __global__ __launch_bounds__(256) void dc_vectors(const MergeDesc* __restrict__ 
   double ss = 0.0;
   for (int r = threadIdx.x; r < d.K; r += 256) {
     const double v = zh[r] / ((dlam[base + pole_of_row[base + r]] - dj) - tj);
-    u[r] = v;
     ss += v * v;
   }
   ss = bsum256(ss, sh);
   const double inv = 1.0 / sqrt(ss);
-  for (int r = threadIdx.x; r < d.K; r += 256) u[r] *= inv;
+  double a = 0.0, b = 0.0;
+  for (int r = threadIdx.x; r < d.K; r += 256) {
+    const double v = zh[r] / ((dlam[base + pole_of_row[base + r]] - dj) - tj);
+    const double un = v * inv;
+    u[r] = un;
+    if (gf != nullptr) {       // (uniform)
+      a += gf[base + r] * un;
+      b += gl[base + r] * un;
+    }
+  }
+  if (gf != nullptr) {
+    a = bsum256(a, sh);
+    b = bsum256(b, sh);
+    if (threadIdx.x == 0) { of[base + cp] = a; ol[base + cp] = b; }
+  }
 }
 
 __global__ void dc_copy_deflated(const MergeDesc* __restrict__ descs,
@@ -1556,12 +1576,27 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
     // takes its copy of a pageable source before it returns, at every size, also in bursts and under load:
     // tools/pageable_h2d_probe.hip, BIGKRLS_FAULT=dc_gd_clobber -- but nothing in the API promises it.)
     std::vector<GemmDesc> gd;
+    if (u_to_stash) {
+      // the children's first / last rows gathered into the order of the merge's secular-vector rows: dc_vectors pushes
+      // them through the merge in the pass that writes the vectors
+      std::vector<double> gfh(n, 0.0), glh(n, 0.0);
+      for (int q = 0; q < nm; ++q) {
+        const MergeDesc& md = descs[q];
+        for (int i = 0; i < md.K; ++i) {
+          gfh[md.s + i] = yf[md.s + A.srccol[md.s + i]];
+          glh[md.s + i] = yl[md.s + A.srccol[md.s + i]];
+        }
+      }
+      BK_TRY(stage.put(d_gf, gfh.data(), n * sizeof(double)));
+      BK_TRY(stage.put(d_gl, glh.data(), n * sizeof(double)));
+    }
     if (maxKneed > 0) {
       for (int b0 = 0; b0 < nm; b0 += 65535) {
         const int nb = std::min(65535, nm - b0);
         hipLaunchKernelGGL(dc_vectors, dim3(maxKneed, nb), dim3(256), 0, st,
                            (const MergeDesc*)(d_descs + b0), (const double*)d_zhat, (const double*)d_dlam,
-                           (const int*)d_pole, (const double*)d_dorg, (const double*)d_tau, Ubase);
+                           (const int*)d_pole, (const double*)d_dorg, (const double*)d_tau, Ubase,
+                           u_to_stash ? (const double*)d_gf : (const double*)nullptr, (const double*)d_gl, d_of, d_ol);
       }
       BK_CHECK_LAUNCH();
     }
@@ -1580,25 +1615,6 @@ int divide_conquer(bigkrls_ctx* ctx, int n, const std::vector<double>& hd,
         // the secular-vector blocks were written straight into the stash (the idle ping-pong copy of Q: the U buffer is
         // reused by the next level); push the boundary rows through the merge
         L.stash_off = level_stash_off;
-        std::vector<double> gfh(n, 0.0), glh(n, 0.0);
-        for (int q = 0; q < nm; ++q) {
-          const MergeDesc& md = descs[q];
-          for (int i = 0; i < md.K; ++i) {
-            gfh[md.s + i] = yf[md.s + A.srccol[md.s + i]];
-            glh[md.s + i] = yl[md.s + A.srccol[md.s + i]];
-          }
-        }
-        BK_TRY(stage.put(d_gf, gfh.data(), n * sizeof(double)));
-        BK_TRY(stage.put(d_gl, glh.data(), n * sizeof(double)));
-        if (maxK > 0) {
-          for (int b0 = 0; b0 < nm; b0 += 65535) {
-            const int nb = std::min(65535, nm - b0);
-            hipLaunchKernelGGL(dc_rows_times_u, dim3(maxK, nb), dim3(256), 0, st,
-                               (const MergeDesc*)(d_descs + b0), (const double*)d_gf, (const double*)d_gl,
-                               (const double*)Ubase, d_of, d_ol);
-          }
-          BK_CHECK_LAUNCH();
-        }
         std::vector<double> ofh(n), olh(n);
         PinnedFetch pf(ctx, 2 * (int64_t)n);
         BK_TRY(pf.add(ofh.data(), d_of, n * sizeof(double)));
@@ -2850,11 +2866,6 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(side_stream_get(ctx));
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
-    int h_err = 0;
-    PinnedFetch pf2(ctx, 1);
-    BK_TRY(pf2.add(&h_err, bc_err, sizeof(int)));
-    BK_TRY(pf2.finish());              // (also: plan.soff (host) was the source of an async copy)
-    tick("stage 2 (band -> tridiagonal)");
     // T factors of the stage-2 back-transform tasks (BIGKRLS_BT2=seq: reflector-by-reflector kernel)
     const char* bt2_env = getenv("BIGKRLS_BT2");
     if (n_vecs_max > 0 && n >= 3 && !(bt2_env && std::string(bt2_env) == "seq")) {
@@ -2865,7 +2876,8 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
                     (ntasks * BT2_G * BT2_G + (int64_t)bt2_toff.size() + 8) * (int64_t)sizeof(double), &pt2));
       bt2_T = (double*)pt2;
       bt2_dtoff = (int64_t*)(bt2_T + ntasks * BT2_G * BT2_G);
-      // on the look-ahead stream: they are not needed before the divide & conquer has finished
+      // on the look-ahead stream, behind the bulge chasing (queued now, while it runs: issuing the ~900 launches of the
+      // merged blocks below takes the host 4 ms): they are not needed before the divide & conquer has finished
       BK_TRY(side_stream_get(ctx));
       hipStream_t side = ctx->side_stream;
       BK_HIP(hipEventRecord(ctx->ev_fork, st));          // the bulge chasing is done
@@ -2877,7 +2889,7 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_CHECK_LAUNCH();
       BK_HIP(hipEventRecord(ctx->ev_join2, side));       // what the stage-2 back-transform waits for
     }
-    if (bt1_grouped && h_err == 0) {
+    if (bt1_grouped) {
       // The merged block reflectors of the stage-1 back-transform, on the look-ahead stream BEHIND the T factors above
       // (round 6): after the bulge chasing (its workgroups fill every CU's LDS; sharing the GPU only slows it down),
       // beside the divide & conquer -- and, since that takes 17 ms at N = 20 000 and these launches 20, beside the first
@@ -2887,9 +2899,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
                             ctx->side_stream));
       BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
-    } else if (bt1_grouped) {
-      bt1_V = nullptr;               // (the decomposition is about to be redone)
     }
+    int h_err = 0;
+    PinnedFetch pf2(ctx, 1);
+    BK_TRY(pf2.add(&h_err, bc_err, sizeof(int)));
+    BK_TRY(pf2.finish());              // (also: plan.soff (host) was the source of an async copy)
+    tick("stage 2 (band -> tridiagonal)");
     if (h_err != 0 && mode == EIG_RESUME) {
       set_error("eigen: watchdog of the LDS-resident bulge chasing fired after the distributed stage 1");
       return BK_EWATCHDOG;

@@ -1,6 +1,6 @@
-# round 6, GPU call 4: the look-ahead stream builds the stage-2 back-transform's T factors first and the merged stage-1
+# round 6, GPU calls 4 and 5: the look-ahead stream builds the stage-2 back-transform's T factors first and the merged stage-1
 # blocks behind them (the stage-2 back-transform no longer waits for the latter) -- tests, bench lines, phase times
-O=gpurun_out/${EVID:-r06e}; mkdir -p $O
+O=gpurun_out/${EVID:-r06f}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q --durations=8 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
