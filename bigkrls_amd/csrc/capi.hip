@@ -63,6 +63,7 @@ int ws_poison_all(bigkrls_ctx* ctx) {
   if (!ws_poison()) return BIGKRLS_OK;
   BK_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->side_stream && !ctx->side_is_main) BK_HIP(hipStreamSynchronize(ctx->side_stream));
+  if (ctx->bg_stream && !ctx->side_is_main) BK_HIP(hipStreamSynchronize(ctx->bg_stream));
   for (int i = 0; i < bigkrls_ctx::kSlots; ++i)
     if (ctx->ws[i] && i != SLOT_COMM_SMALL) BK_HIP(hipMemsetAsync(ctx->ws[i], 0xFF, (size_t)ctx->ws_bytes[i], ctx->stream));
   BK_HIP(hipStreamSynchronize(ctx->stream));
@@ -172,6 +173,7 @@ int side_stream_get(bigkrls_ctx* ctx) {
     // nondeterminism (tools/oversub_single.py --arms).
     if (getenv("BIGKRLS_NO_SIDE")) {
       ctx->side_stream = ctx->stream;
+      ctx->bg_stream = ctx->stream;
       ctx->side_is_main = true;
       BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
       BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -184,6 +186,7 @@ int side_stream_get(bigkrls_ctx* ctx) {
     int prio_lo = 0, prio_hi = 0;
     BK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     BK_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
+    BK_HIP(hipStreamCreateWithPriority(&ctx->bg_stream, hipStreamNonBlocking, prio_lo));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     BK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
@@ -227,6 +230,7 @@ int prof_end(bigkrls_ctx* ctx, const char* name, hipStream_t stream) {
 static int prof_flush(bigkrls_ctx* ctx) {
   BK_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->side_stream) BK_HIP(hipStreamSynchronize(ctx->side_stream));
+  if (ctx->bg_stream) BK_HIP(hipStreamSynchronize(ctx->bg_stream));
   for (auto& e : ctx->prof) {
     for (auto& s : e.pending) {
       float ms = 0.f;
@@ -376,6 +380,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->bg_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->bg_stream);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);

@@ -59,6 +59,9 @@ struct bigkrls_ctx {
   void* dist_s1 = nullptr;
   void (*dist_s1_free)(void*) = nullptr;
   hipStream_t side_stream = nullptr;
+  // lowest-priority stream for work nobody waits for soon (what is precomputed for the back-transforms while the divide
+  // & conquer runs: its kernels must not take compute units from the critical path's); created with the side stream
+  hipStream_t bg_stream = nullptr;
   bool side_is_main = false;   // BIGKRLS_NO_SIDE (diagnostics): side_stream is the main stream itself
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_pq = nullptr;
   // workspace slots: slot i is grown on demand and reused across calls

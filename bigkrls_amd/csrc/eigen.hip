@@ -2490,6 +2490,7 @@ static int eigen_retry_without_resident(bigkrls_ctx* ctx, const double* A, int64
                                         double* vecs, int64_t ldv, int64_t* h_n_vecs, int part_index,
                                         int part_count) {
   if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);   // look-ahead work still queued
+  if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->no_resident) {
     set_error("eigen: watchdog of a persistent kernel fired although none should have been launched");
@@ -2866,6 +2867,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(side_stream_get(ctx));
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
+    // (BIGKRLS_BG=0, an A/B switch: what is precomputed for the back-transforms goes to the high-priority look-ahead
+    //  stream, as before round 6, instead of the lowest-priority one)
+    auto pre_stream = [&]() -> hipStream_t {
+      static const bool bg = [] { const char* e = getenv("BIGKRLS_BG"); return !(e && e[0] == '0'); }();
+      return bg ? ctx->bg_stream : ctx->side_stream;
+    };
     // T factors of the stage-2 back-transform tasks (BIGKRLS_BT2=seq: reflector-by-reflector kernel)
     const char* bt2_env = getenv("BIGKRLS_BT2");
     if (n_vecs_max > 0 && n >= 3 && !(bt2_env && std::string(bt2_env) == "seq")) {
@@ -2878,8 +2885,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       bt2_dtoff = (int64_t*)(bt2_T + ntasks * BT2_G * BT2_G);
       // on the look-ahead stream, behind the bulge chasing (queued now, while it runs: issuing the ~900 launches of the
       // merged blocks below takes the host 4 ms): they are not needed before the divide & conquer has finished
+      // ... and on the LOWEST-priority stream: whatever the divide & conquer launches meanwhile goes first (on the
+      // look-ahead stream, which has the highest priority, this kernel's 97 000 workgroups held the divide & conquer's
+      // first levels back by 2-4 ms)
       BK_TRY(side_stream_get(ctx));
-      hipStream_t side = ctx->side_stream;
+      hipStream_t side = pre_stream();
       BK_HIP(hipEventRecord(ctx->ev_fork, st));          // the bulge chasing is done
       BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
       BK_HIP(hipMemcpyAsync(bt2_dtoff, bt2_toff.data(), bt2_toff.size() * sizeof(int64_t), hipMemcpyHostToDevice, side));
@@ -2895,10 +2905,9 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // beside the divide & conquer -- and, since that takes 17 ms at N = 20 000 and these launches 20, beside the first
       // milliseconds of the stage-2 back-transform, which no longer waits for them: only the stage-1 back-transform does.
       BK_HIP(hipEventRecord(ctx->ev_fork, st));
-      BK_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1,
-                            ctx->side_stream));
-      BK_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+      BK_HIP(hipStreamWaitEvent(pre_stream(), ctx->ev_fork, 0));
+      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1, pre_stream()));
+      BK_HIP(hipEventRecord(ctx->ev_join, pre_stream()));
     }
     int h_err = 0;
     PinnedFetch pf2(ctx, 1);

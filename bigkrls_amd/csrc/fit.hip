@@ -337,6 +337,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
         fprintf(stderr, "[bigkrls] rank %d: %s; replaying the distributed decomposition with per-step launches\n",
                 comm->rank, bigkrls_last_error());
       if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+      if (ctx->bg_stream) (void)hipStreamSynchronize(ctx->bg_stream);
       (void)hipStreamSynchronize(st);
       ctx->n_replayed++;
       ctx->no_resident = true;

@@ -492,7 +492,7 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
   if (splits > 1) {
     void* p = nullptr;
     // GEMMs issued on the look-ahead stream run concurrently with main-stream GEMMs: own partial buffer
-    const int slot = (ctx->side_stream && ctx->stream == ctx->side_stream) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
+    const int slot = (ctx->side_stream && (ctx->stream == ctx->side_stream || ctx->stream == ctx->bg_stream)) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
     BK_TRY(ws_get(ctx, slot, (int64_t)splits * g.M * g.N * sizeof(double), &p));
     partial = (double*)p;
   }
@@ -673,7 +673,7 @@ int gemm_nn_skinny48(bigkrls_ctx* ctx, int64_t m, int64_t n, int64_t k, const do
   int k_chunk = (int)(((k + splits - 1) / splits + BK - 1) / BK * BK);
   splits = (int)((k + k_chunk - 1) / k_chunk);
   void* p = nullptr;
-  const int slot = (ctx->side_stream && ctx->stream == ctx->side_stream) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
+  const int slot = (ctx->side_stream && (ctx->stream == ctx->side_stream || ctx->stream == ctx->bg_stream)) ? SLOT_SIDE_SPLITK : SLOT_GEMM_SPLITK;
   BK_TRY(ws_get(ctx, slot, (int64_t)splits * m * n * sizeof(double), &p));
   BK_TRY(ensure_dyn_smem(ctx, (const void*)gemm_nn48_kernel, sk48_smem_bytes()));
   hipLaunchKernelGGL(gemm_nn48_kernel, dim3(tiles_m, splits), dim3(NT), sk48_smem_bytes(), ctx->stream, g, tiles_m, k_chunk,
