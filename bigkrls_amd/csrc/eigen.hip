@@ -2867,10 +2867,11 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       BK_TRY(side_stream_get(ctx));
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
-    // (BIGKRLS_BG=0, an A/B switch: what is precomputed for the back-transforms goes to the high-priority look-ahead
-    //  stream, as before round 6, instead of the lowest-priority one)
+    // (BIGKRLS_BG=1, an A/B switch: what is precomputed for the back-transforms goes to a lowest-priority stream instead
+    //  of the high-priority look-ahead stream. Measured slower: C3 0.4029-0.4043 vs 0.4009-0.4012 s, same box
+    //  (profiles/r06/r06g_bg_stream_ab_*.log) -- the merged blocks then finish late behind the stage-2 back-transform)
     auto pre_stream = [&]() -> hipStream_t {
-      static const bool bg = [] { const char* e = getenv("BIGKRLS_BG"); return !(e && e[0] == '0'); }();
+      static const bool bg = [] { const char* e = getenv("BIGKRLS_BG"); return e && e[0] == '1'; }();
       return bg ? ctx->bg_stream : ctx->side_stream;
     };
     // T factors of the stage-2 back-transform tasks (BIGKRLS_BT2=seq: reflector-by-reflector kernel)
@@ -2885,17 +2886,16 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       bt2_dtoff = (int64_t*)(bt2_T + ntasks * BT2_G * BT2_G);
       // on the look-ahead stream, behind the bulge chasing (queued now, while it runs: issuing the ~900 launches of the
       // merged blocks below takes the host 4 ms): they are not needed before the divide & conquer has finished
-      // ... and on the LOWEST-priority stream: whatever the divide & conquer launches meanwhile goes first (on the
-      // look-ahead stream, which has the highest priority, this kernel's 97 000 workgroups held the divide & conquer's
-      // first levels back by 2-4 ms)
       BK_TRY(side_stream_get(ctx));
       hipStream_t side = pre_stream();
       BK_HIP(hipEventRecord(ctx->ev_fork, st));          // the bulge chasing is done
       BK_HIP(hipStreamWaitEvent(side, ctx->ev_fork, 0));
       BK_HIP(hipMemcpyAsync(bt2_dtoff, bt2_toff.data(), bt2_toff.size() * sizeof(int64_t), hipMemcpyHostToDevice, side));
       const int ngroups = (int)bt2_toff.size() - 1, ntmax = (n - 2) / S2_B + 1;
-      hipLaunchKernelGGL(bt2_build_t, dim3(ntmax, ngroups), dim3(256), 0, side, n, (const int64_t*)d_soff,
-                         (const double*)VV, (const double*)TT, (const int64_t*)bt2_dtoff, bt2_T);
+      BK_TRY(ensure_dyn_smem(ctx, (const void*)bt2_build_t, BT2T_SMEM));
+      hipLaunchKernelGGL(bt2_build_t, dim3((unsigned)(((int64_t)ntmax * ngroups + 3) / 4)), dim3(256), BT2T_SMEM, side, n,
+                         (const int64_t*)d_soff, (const double*)VV, (const double*)TT, (const int64_t*)bt2_dtoff, bt2_T,
+                         ntmax, ngroups);
       BK_CHECK_LAUNCH();
       BK_HIP(hipEventRecord(ctx->ev_join2, side));       // what the stage-2 back-transform waits for
     }
