@@ -378,6 +378,7 @@ int bigkrls_ctx_destroy(bigkrls_ctx* ctx) {
   if (ctx->dist_s1 && ctx->dist_s1_free) ctx->dist_s1_free(ctx->dist_s1);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->side_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->bg_stream && !ctx->side_is_main) (void)hipStreamDestroy(ctx->bg_stream);

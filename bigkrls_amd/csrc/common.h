@@ -74,6 +74,9 @@ struct bigkrls_ctx {
   // pinned arena the small host -> device uploads of the divide & conquer go through (PinnedStage)
   char* h_stage = nullptr;
   int64_t h_stage_bytes = 0;
+  // ... and the small pinned buffer the group table of the stage-1 back-transform's precompute is uploaded from
+  char* h_plan = nullptr;
+  int64_t h_plan_bytes = 0;
   // optional HIP-event sampling of named kernels (bench.py roofline numbers)
   bool profile = false;
   struct ProfSample { hipEvent_t e0, e1; double work; };

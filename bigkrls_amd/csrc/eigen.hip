@@ -2859,11 +2859,14 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       bt1 = bt1_plan(n);
       void *pvb = nullptr, *ptb = nullptr;
       BK_TRY(ws_get(ctx, SLOT_EIG_VBIG, (bt1.vtotal + 16) * (int64_t)sizeof(double), &pvb));
+      // per group: the merged T (LT x LT), its Gram matrix (LT x LT), the recurrence's scratch (LT x 64); then the group table
+      const int64_t ng1 = (int64_t)bt1.k0.size();
       BK_TRY(ws_get(ctx, SLOT_EIG_TBIG,
-                    ((int64_t)bt1.k0.size() * LT1 * LT1 + 2 * LT1 * LT1) * (int64_t)sizeof(double), &ptb));
+                    (ng1 * (2 * LT1 * LT1 + LT1 * S2_B) + 16) * (int64_t)sizeof(double) + (ng1 + 1) * (int64_t)sizeof(Bt1Group),
+                    &ptb));
       bt1_V = (double*)pvb;
       bt1_T = (double*)ptb;
-      bt1_G = bt1_T + (int64_t)bt1.k0.size() * LT1 * LT1;
+      bt1_G = bt1_T + ng1 * LT1 * LT1;
       BK_TRY(side_stream_get(ctx));
     }
     BK_TRY(stage2_to_tridiag(ctx, AB, n, d_soff, VV, TT, d, e, (int*)tau, bc_err));
@@ -2906,7 +2909,12 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
       // milliseconds of the stage-2 back-transform, which no longer waits for them: only the stage-1 back-transform does.
       BK_HIP(hipEventRecord(ctx->ev_fork, st));
       BK_HIP(hipStreamWaitEvent(pre_stream(), ctx->ev_fork, 0));
-      BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_G + LT1 * LT1, pre_stream()));
+      {
+        const int64_t ng1 = (int64_t)bt1.k0.size();
+        double* bt1_tmp = bt1_G + ng1 * LT1 * LT1;
+        Bt1Group* d_groups = (Bt1Group*)(bt1_tmp + ng1 * LT1 * S2_B + 8);
+        BK_TRY(bt1_precompute(ctx, W, n, taus1, s1.Tall, bt1, bt1_V, bt1_T, bt1_G, bt1_tmp, d_groups, pre_stream()));
+      }
       BK_HIP(hipEventRecord(ctx->ev_join, pre_stream()));
     }
     int h_err = 0;

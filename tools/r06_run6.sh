@@ -1,5 +1,5 @@
 # round 6, GPU calls 6 and 7: the precompute for the back-transforms on the look-ahead stream (BIGKRLS_BG=1: on a lowest-priority stream; call 6 had the default the other way round) -- tests, same-box A/B at three sizes, phase times; call 7 with bt2_build_t as one wave per task
-O=gpurun_out/${EVID:-r06h}; mkdir -p $O
+O=gpurun_out/${EVID:-r06i}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q --durations=8 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
