@@ -67,7 +67,7 @@ def parse():
                     help="comma-separated 1-based columns, e.g. 1,3,5")
     ap.add_argument("--cpu-n", type=int, default=None,
                     help="rows of the CPU-baseline sample (default: the bench N for C2/C3)")
-    ap.add_argument("--cpu-budget-s", type=float, default=800.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=880.0,
                     help="wall-clock bound of the CPU baseline; what is measured until then is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
