@@ -930,29 +930,6 @@ __global__ void dc_gather_rows(const MergeDesc* __restrict__ descs, const double
   yl[d.s + t] = (t < d.n1) ? 0.0 : Q[d.s + d.m - 1 + col];
 }
 
-// of[s+j] = sum_i gf[s+i] U[i,j], ol likewise: first / last row of the merged eigenvector matrix
-// (non-deflated columns) from the gathered, rotated rows of the children -- one block per column
-__global__ __launch_bounds__(256) void dc_rows_times_u(const MergeDesc* __restrict__ descs,
-                                                       const double* __restrict__ gf,
-                                                       const double* __restrict__ gl,
-                                                       const double* __restrict__ U,
-                                                       double* __restrict__ of, double* __restrict__ ol) {
-  __shared__ double sh[4];
-  const MergeDesc d = descs[blockIdx.y];
-  const int j = blockIdx.x;
-  if (j >= d.K) return;
-  const double* u = U + d.uoff + (int64_t)j * d.uld;
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < d.K; i += 256) {
-    const double v = u[i];
-    a += gf[d.s + i] * v;
-    b += gl[d.s + i] * v;
-  }
-  a = bsum256(a, sh);
-  b = bsum256(b, sh);
-  if (threadIdx.x == 0) { of[d.s + j] = a; ol[d.s + j] = b; }
-}
-
 // X[:, t] = column src_cols[t] of the root's merge operator (X zeroed beforehand): a non-deflated
 // column c < K carries U[:, c] in the rows srccol, a deflated one is a unit vector
 __global__ void dc_lazy_root_x(int nv, const int* __restrict__ cols, int K,
