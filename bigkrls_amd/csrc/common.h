@@ -310,7 +310,7 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n_rows, int64_t k, 
 // ---- deriv.hip ----------------------------------------------------------------
 int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
                int64_t row0, const double* X, int64_t p, int64_t ldx, const int32_t* h_is_binary,
-               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds);
+               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out = nullptr);
 int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
               const double* wv, const double* S, int64_t p, int64_t lds, const double* h_scale,
               double* h_var);

@@ -116,7 +116,7 @@ __global__ void deriv_finalize_kernel(int n_rows, int p, int row0, const double*
 
 int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
                int64_t row0, const double* X, int64_t p, int64_t ldx, const int32_t* h_is_binary,
-               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds) {
+               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out) {
   BK_REQUIRE(n > 0 && n_rows > 0 && p > 0 && n < (1ll << 31) && p < (1 << 20),
              "deriv_rows: bad dimensions");
   BK_REQUIRE(row0 >= 0 && row0 + n_rows <= n, "deriv_rows: row block out of range");
@@ -128,8 +128,12 @@ int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows,
   BK_TRY(ws_get(ctx, SLOT_DERIV_T, (2 * p + 8) * sizeof(double) + p * sizeof(int32_t), &pt));
   double* minmax = (double*)pt;
   int* d_isbin = (int*)(minmax + 2 * p + 8);
-  BK_HIP(hipMemcpyAsync(d_isbin, h_is_binary, p * sizeof(int32_t), hipMemcpyHostToDevice,
-                        ctx->stream));
+  {
+    // (through the context's pinned upload arena: no asynchronous copy out of the caller's pageable memory)
+    PinnedStage up(ctx);
+    BK_TRY(up.reserve((size_t)p * sizeof(int32_t) + 256));
+    BK_TRY(up.put(d_isbin, h_is_binary, (size_t)p * sizeof(int32_t)));
+  }
   hipLaunchKernelGGL(col_minmax_kernel, dim3((unsigned)p), dim3(256), 0, ctx->stream, (int)n, X,
                      ldx, minmax);
   BK_CHECK_LAUNCH();
@@ -154,7 +158,11 @@ int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows,
                      (int)p, (int)row0, X, ldx, (const int*)d_isbin, (const double*)minmax,
                      (const double*)pkb, sigma, D, ldd, S, lds);
   BK_CHECK_LAUNCH();
-  // h_is_binary was consumed by an async copy: make sure it is done before returning
+  // K c is column 1 of the product: the caller's fitted values (R/bigKRLS.R:291) without a pass over K of their own
+  if (kc_out != nullptr)
+    BK_HIP(hipMemcpyAsync(kc_out, (const double*)pkb + n_rows, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice,
+                          ctx->stream));
+  // (the upload arena and the product buffers are free again when this returns)
   BK_HIP(hipStreamSynchronize(ctx->stream));
   return BIGKRLS_OK;
 }

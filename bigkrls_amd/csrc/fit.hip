@@ -608,11 +608,36 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
 
   // ---- step 4: coefficients, fitted values (:286-291) -----------------------------------------------
   double Le = 0.0;
+  // the columns of the marginal-effects pass (step 5), decided here because on one GPU that pass -- ONE product of K
+  // with [1, c, x_j, x_j o c ...] -- also delivers K c, the fitted values: no pass over K of their own (round 6;
+  // 0.55 ms at N = 20 000, 13 ms at N = 100 000)
+  std::vector<int32_t> isbin(pd);
+  std::vector<double> scale(pd), var(pd);
+  for (int64_t i = 0; i < pd; ++i) {
+    const double* x = Xs.data() + cols[i] * n;
+    double lo, hi;
+    isbin[i] = two_valued(x, n, &lo, &hi) ? 1 : 0;                                                     // src/bigderiv_v3.cpp:28-31
+    if (isbin[i]) {
+      const double sd = 1.0 / (hi - lo);                                                               // :36
+      scale[i] = 2.0 * sd * sd / ((double)n * (double)n);                                              // :85
+    } else {
+      scale[i] = 4.0 / (sigma * sigma * (double)n * (double)n);                                        // :105
+    }
+  }
+  const bool yhat_from_deriv = !comm && derivative;
   if (!comm) {
     BK_TRY(solveforc(ctx, dQ, n, k, n, dvals, da, lambda, dc, &Le));
-    if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
-    BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                            // yfitted = K c (full K)
-    if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
+    if (yhat_from_deriv) {
+      for (int64_t i = 0; i < pd; ++i) std::memcpy(pin + i * n, Xs.data() + cols[i] * n, (size_t)n * sizeof(double));   // X_estimate (:326)
+      BK_TRY(upload(ctx, dXe, pin, n * pd));
+      if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
+      BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n, dyhat));   // + yfitted = K c (:291)
+      if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
+    } else {
+      if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
+      BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                          // yfitted = K c (full K)
+      if (ctx->profile) BK_TRY(prof_end(ctx, "yhat_gemv"));
+    }
   } else {
     // own rows of c and of K c (K symmetric: K[:, r0:r1)' c), one all-gather each; Le is a sum over the row blocks
     BK_TRY(agreed(nloc > 0 ? solveforc(ctx, dQ + r0, nloc, k, n, dvals, da, lambda, dDloc, &Le) : BIGKRLS_OK));
@@ -704,25 +729,12 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   // ---- step 5: marginal effects (:321-376) and their post-processing (:384-409) -----------------------
   out->R2AME = NaN;
   if (derivative) {
-    std::vector<int32_t> isbin(pd);
-    std::vector<double> scale(pd), var(pd);
-    for (int64_t i = 0; i < pd; ++i) {
-      const double* x = Xs.data() + cols[i] * n;
-      std::memcpy(pin + i * n, x, (size_t)n * sizeof(double));                                         // X_estimate (:326)
-      double lo, hi;
-      isbin[i] = two_valued(x, n, &lo, &hi) ? 1 : 0;                                                   // src/bigderiv_v3.cpp:28-31
-      if (isbin[i]) {
-        const double sd = 1.0 / (hi - lo);                                                             // :36
-        scale[i] = 2.0 * sd * sd / ((double)n * (double)n);                                            // :85
-      } else {
-        scale[i] = 4.0 / (sigma * sigma * (double)n * (double)n);                                      // :105
-      }
+    if (comm) {
+      for (int64_t i = 0; i < pd; ++i) std::memcpy(pin + i * n, Xs.data() + cols[i] * n, (size_t)n * sizeof(double));   // X_estimate (:326)
+      BK_TRY(upload(ctx, dXe, pin, n * pd));
     }
-    BK_TRY(upload(ctx, dXe, pin, n * pd));
     if (!comm) {
-      if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
-      BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n));
-      if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
+      // (the pass over K ran in step 4, where it also produced the fitted values)
     } else {
       // own rows of D and S from the own column block, one all-gather of each (N x P')
       const int64_t ldl = std::max<int64_t>(nloc, 1);
