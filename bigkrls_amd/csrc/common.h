@@ -182,6 +182,7 @@ enum Slot {
   SLOT_DIST_K = 40,        // ... this rank's column block of K when the caller does not want it back
   SLOT_DIST_V = 41,        // ... column blocks of the variance matrices (same)
   SLOT_EIG_FLAGS = 42,     // completion flags of the persistent stage-2 back-transform's tasks
+  SLOT_FIT_VERIFY = 43,    // the fit's check of a decomposition against K: Q r, Q (lambda o r), K Q r
 };
 
 int ws_get(bigkrls_ctx* ctx, int slot, int64_t nbytes, void** out);
@@ -310,7 +311,8 @@ int lambda_search(bigkrls_ctx* ctx, const double* Q, int64_t n_rows, int64_t k, 
 // ---- deriv.hip ----------------------------------------------------------------
 int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
                int64_t row0, const double* X, int64_t p, int64_t ldx, const int32_t* h_is_binary,
-               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out = nullptr);
+               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out = nullptr,
+               const double* extra = nullptr, int64_t n_extra = 0, double* extra_out = nullptr);
 int deriv_var(bigkrls_ctx* ctx, const double* Q, int64_t n, int64_t k, int64_t ldq,
               const double* wv, const double* S, int64_t p, int64_t lds, const double* h_scale,
               double* h_var);

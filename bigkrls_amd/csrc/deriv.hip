@@ -116,12 +116,17 @@ __global__ void deriv_finalize_kernel(int n_rows, int p, int row0, const double*
 
 int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows, int64_t ldk,
                int64_t row0, const double* X, int64_t p, int64_t ldx, const int32_t* h_is_binary,
-               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out) {
+               const double* c, double sigma, double* D, int64_t ldd, double* S, int64_t lds, double* kc_out,
+               const double* extra, int64_t n_extra, double* extra_out) {
+  // `extra` (n x n_extra, ld n): more operand columns for the same pass over K; K extra -> extra_out (n_rows x n_extra).
+  // The fit sends the two +-1 combinations of its kept eigenvectors along: the check of the decomposition against K
+  // costs no pass over K of its own (csrc/fit.hip).
   BK_REQUIRE(n > 0 && n_rows > 0 && p > 0 && n < (1ll << 31) && p < (1 << 20),
              "deriv_rows: bad dimensions");
   BK_REQUIRE(row0 >= 0 && row0 + n_rows <= n, "deriv_rows: row block out of range");
   BK_REQUIRE(Krows && X && h_is_binary && c && D && S, "deriv_rows: null pointer");
-  const int64_t nb = 2 + 2 * p;
+  BK_REQUIRE(n_extra >= 0 && (n_extra == 0 || (extra && extra_out)), "deriv_rows: bad extra operand");
+  const int64_t nb0 = 2 + 2 * p, nb = nb0 + n_extra;
   void *pb = nullptr, *pkb = nullptr, *pt = nullptr;
   BK_TRY(ws_get(ctx, SLOT_DERIV_B, n * nb * sizeof(double), &pb));
   BK_TRY(ws_get(ctx, SLOT_DERIV_KB, n_rows * nb * sizeof(double), &pkb));
@@ -141,6 +146,9 @@ int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows,
   hipLaunchKernelGGL(build_b_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, (int)p, X,
                      ldx, c, (const int*)d_isbin, (const double*)minmax, (double*)pb);
   BK_CHECK_LAUNCH();
+  if (n_extra > 0)
+    BK_HIP(hipMemcpyAsync((double*)pb + nb0 * n, extra, (size_t)(n * n_extra) * sizeof(double), hipMemcpyDeviceToDevice,
+                          ctx->stream));
   // KB (n_rows x nb) = Krows' (n_rows x n) * B (n x nb). The whole (exactly symmetric) K: K B, the product that
   // streams K along its contiguous dimension (the transposed-operand GEMM runs at about a third of its rate)
   // (33 .. 48 operand columns -- P = 16 .. 23 -- on the 128 x 48 tile: the 128 x 64 tile of gemm() would run the MFMA
@@ -162,6 +170,9 @@ int deriv_rows(bigkrls_ctx* ctx, const double* Krows, int64_t n, int64_t n_rows,
   if (kc_out != nullptr)
     BK_HIP(hipMemcpyAsync(kc_out, (const double*)pkb + n_rows, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice,
                           ctx->stream));
+  if (n_extra > 0)
+    BK_HIP(hipMemcpyAsync(extra_out, (const double*)pkb + nb0 * n_rows, (size_t)(n_rows * n_extra) * sizeof(double),
+                          hipMemcpyDeviceToDevice, ctx->stream));
   // (the upload arena and the product buffers are free again when this returns)
   BK_HIP(hipStreamSynchronize(ctx->stream));
   return BIGKRLS_OK;

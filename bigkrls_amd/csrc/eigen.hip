@@ -988,6 +988,11 @@ __global__ void dc_fault_spin(long long ticks) {
 }
 // test build only: one eigenvalue moved to the next representable double (a last-bit deviation of ONE rank's replica)
 __global__ void fault_nudge_ulp(double* v) { *v = nextafter(*v, 2.0 * *v + 1.0); }
+// test build only: two eigenvector columns exchanged (orthonormal columns, right eigenvalues, wrong pairing)
+__global__ void fault_swap_cols(double* a, double* b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double t = a[i]; a[i] = b[i]; b[i] = t; }
+}
 #endif
 __global__ void dc_iota(int* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3002,6 +3007,18 @@ int eigen(bigkrls_ctx* ctx, const double* A, int64_t n64, int64_t lda, int64_t n
     const int gc = part_count == 1 ? nv / 2 : nv - 1;
     if ((always || (once && garbage_calls++ == 0)) && nv > 0 && n_vecs_max > 0 && part_index == part_count - 1)
       BK_TRY(scale(ctx, N, 1.001, vecs + (int64_t)gc * ldv));
+    // BIGKRLS_FAULT=eig_swap / eig_swap_always: two kept eigenvectors exchanged -- every column still has norm 1, the
+    // combinations Q r keep |Q r|^2 = k: only the comparison with K Q r (on one GPU deferred to the fit's pass over K
+    // for the marginal effects, csrc/fit.hip) can see it
+    {
+      static int swap_calls = 0;
+      const bool sonce = fault && std::string(fault) == "eig_swap", salways = fault && std::string(fault) == "eig_swap_always";
+      if (!sonce && !salways) swap_calls = 0;
+      if ((salways || (sonce && swap_calls++ == 0)) && nv > 3 && n_vecs_max > 0 && part_count == 1 && keep_thresh >= 0.0) {
+        fault_swap_cols<<<(N + 255) / 256, 256, 0, st>>>(vecs + (int64_t)(nv / 2) * ldv, vecs + (int64_t)(nv / 2 + 1) * ldv, (int)N);
+        BK_HIP(hipGetLastError());
+      }
+    }
     // BIGKRLS_FAULT=vals_ulp (set in ONE rank's process): this rank's copy of the replicated eigenvalues differs from its
     // peers' in the last bit of one kept value -- a valid decomposition the fit's check against K lets through; the
     // multi-GPU fit must still run its lambda search on identical values everywhere (csrc/fit.hip: rank 0's are broadcast)

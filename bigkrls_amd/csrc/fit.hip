@@ -84,6 +84,11 @@ struct PhaseTimer {
     if (hipEventRecord(ev[n], ctx->stream) != hipSuccess) ok = false;
     ++n;
   }
+  void rewind(int to) {   // (a phase is run again: its events and the later ones are recorded anew)
+    for (int i = to; i < n; ++i)
+      if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+    if (to < n) n = to;
+  }
   void collect(double* out8) {
     for (int i = 0; i < 8; ++i) out8[i] = 0.0;
     if (!ok) return;
@@ -435,9 +440,21 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   // 1e-7 lambda_1 sqrt(k) (the iteration accepts true residuals up to 1e-9 lambda_1 per pair): one more pass over K,
   // +4 ms at N = 50 000, rank-local rows in a multi-GPU fit.
   // BIGKRLS_VERIFY=0 switches the check off (A/B timing).
+  // On one GPU with marginal effects asked for, the product K [u_1 u_2] is DEFERRED (round 6): the combinations ride
+  // along in the one pass over K that step 4 makes anyway (marginal effects + fitted values), and the comparison happens
+  // there (verify_deferred below); what can be checked without K -- the trace, |Q r|^2 = k -- is checked here. If the
+  // deferred comparison fails, everything from the decomposition on is redone once (the lambda search and the
+  // coefficients of a wrong decomposition, 2 ms, are thrown away). One pass over K behind the eigensolver instead of
+  // three: -0.6 ms at N = 20 000, -4.5 ms at N = 50 000, -18 ms at N = 100 000.
+  const bool defer_k = !comm && derivative;
+  bool verify_pending = false;                 // the deferred comparison is still to come
+  double* dVU = nullptr;                       // device: [U | L | R] of the check (SLOT_FIT_VERIFY)
+  std::vector<double> verify_l;                // host copy of L = Q (lambda o r), n x 2
+  double verify_tol = 0.0;
   auto verify = [&]() -> int {
     static const bool on = [] { const char* e = getenv("BIGKRLS_VERIFY"); return !(e && e[0] == '0'); }();
     const bool krylov = neig < n && ((!comm && neig * 8 <= n && n >= 16384) || (comm && dist_mode == DE_KRYLOV));
+    verify_pending = false;
     if (!on || lastkeeper <= 0) return BIGKRLS_OK;
     const double vtol = krylov ? 1e-7 : 1e-8;
     char buf[256];
@@ -456,7 +473,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     const int64_t kk = lastkeeper;
     const int64_t rows = comm ? nloc : n, rr0 = comm ? r0 : 0;
     void* pv = nullptr;
-    BK_TRY(ws_get(ctx, SLOT_DERIV_KB, (6 * n + 4 * kk) * (int64_t)sizeof(double), &pv));
+    BK_TRY(ws_get(ctx, SLOT_FIT_VERIFY, (6 * n + 4 * kk) * (int64_t)sizeof(double), &pv));
     double* dU = (double*)pv;             // n x 2: Q r
     double* dL = dU + 2 * n;              // n x 2: Q (lambda o r)
     double* dR = dL + 2 * n;              // rows x 2: K[rows, :] U
@@ -474,15 +491,21 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     }
     BK_HIP(hipMemcpyAsync(dC, hp, (size_t)(4 * kk) * sizeof(double), hipMemcpyHostToDevice, st));
     BK_TRY(gemm(ctx, 0, 0, n, 4, kk, 1.0, dQ, n, dC, kk, 0.0, dU, n));          // [U | L] = Q [R | Lambda R]  (dL follows dU)
-    if (rows > 0) {
+    if (rows > 0 && !defer_k) {
       if (!comm) BK_TRY(gemm(ctx, 0, 0, n, 2, n, 1.0, dK, n, dU, n, 0.0, dR, n));
       else BK_TRY(gemm(ctx, 1, 0, rows, 2, n, 1.0, dK, n, dU, n, 0.0, dR, rows));
     }
     BK_HIP(hipStreamSynchronize(st));     // (the pinned buffer was the source of the upload)
     BK_HIP(hipMemcpyAsync(hp, dU, (size_t)(4 * n) * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (rows > 0) BK_HIP(hipMemcpyAsync(hp + 4 * n, dR, (size_t)(2 * rows) * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (rows > 0 && !defer_k) BK_HIP(hipMemcpyAsync(hp + 4 * n, dR, (size_t)(2 * rows) * sizeof(double), hipMemcpyDeviceToHost, st));
     BK_HIP(hipStreamSynchronize(st));
     const double scale = std::fabs(vals[0]) > 0.0 ? std::fabs(vals[0]) : 1.0;
+    if (defer_k) {
+      dVU = dU;
+      verify_l.assign(hp + 2 * n, hp + 4 * n);
+      verify_tol = vtol * scale * std::sqrt((double)kk);
+      verify_pending = true;
+    }
     for (int i = 0; i < 2; ++i) {
       const double* u = hp + i * n;
       const double* l = hp + 2 * n + i * n;
@@ -490,7 +513,7 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
       long double nrm = 0.0L;
       for (int64_t t = 0; t < n; ++t) nrm += (long double)u[t] * u[t];
       double worst = 0.0;
-      for (int64_t t = 0; t < rows; ++t) {
+      for (int64_t t = 0; t < (defer_k ? 0 : rows); ++t) {
         const double d = std::fabs(r[t] - l[rr0 + t]);
         worst = (d > worst || d != d) ? d : worst;
       }
@@ -511,6 +534,9 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   // (every decision below is taken by ALL ranks together: after a fault one rank's copy of the replicated eigenvalues
   //  may hold NaNs or no kept pair while its peers' copies are fine -- a rank that left the loop on its own would
   //  leave the others waiting in the next collective)
+  bool deferred_redo_done = false;
+  const int timer_n_before_eigen = timer.n;
+retry_from_eigen:
   bool nan_agreed = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int rc_run = run_eigen();
@@ -631,8 +657,37 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
       for (int64_t i = 0; i < pd; ++i) std::memcpy(pin + i * n, Xs.data() + cols[i] * n, (size_t)n * sizeof(double));   // X_estimate (:326)
       BK_TRY(upload(ctx, dXe, pin, n * pd));
       if (ctx->profile) BK_TRY(prof_begin(ctx, "deriv_rows", 8.0 * (double)n * (double)n));
-      BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n, dyhat));   // + yfitted = K c (:291)
+      BK_TRY(deriv_rows(ctx, dK, n, n, n, 0, dXe, pd, n, isbin.data(), dc, sigma, dD, n, dS, n, dyhat,   // + yfitted = K c (:291)
+                        verify_pending ? dVU : (const double*)nullptr, verify_pending ? 2 : 0,
+                        verify_pending ? dVU + 4 * n : (double*)nullptr));                              // + K [u_1 u_2]
       if (ctx->profile) BK_TRY(prof_end(ctx, "deriv_rows"));
+      if (verify_pending) {
+        // the deferred half of the check of the decomposition against K: |K Q r - Q (lambda o r)| over all rows
+        verify_pending = false;
+        BK_HIP(hipMemcpyAsync(pin, dVU + 4 * n, (size_t)(2 * n) * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipStreamSynchronize(st));
+        double worst = 0.0;
+        for (int64_t t = 0; t < 2 * n; ++t) {
+          const double d = std::fabs(pin[t] - verify_l[t]);
+          worst = (d > worst || d != d) ? d : worst;
+        }
+        if (!(worst <= verify_tol)) {
+          char buf[256];
+          snprintf(buf, sizeof buf, "fit: the %lld kept eigenpairs fail the check against K (|K Q r - Q Lambda r| = %.3e, tolerance %.3e)",
+                   (long long)k, worst, verify_tol);
+          set_error(buf);
+          if (deferred_redo_done) {
+            set_error(std::string(bigkrls_last_error()) + " -- also after the decomposition was redone");
+            return BIGKRLS_EHIP;
+          }
+          if (getenv("BIGKRLS_VERBOSE") || getenv("BIGKRLS_REPORT_REDO"))
+            fprintf(stderr, "[bigkrls] %s; redoing the decomposition\n", bigkrls_last_error());
+          deferred_redo_done = true;
+          ctx->n_redone++;
+          timer.rewind(timer_n_before_eigen);
+          goto retry_from_eigen;
+        }
+      }
     } else {
       if (ctx->profile) BK_TRY(prof_begin(ctx, "yhat_gemv", 8.0 * (double)n * (double)n));
       BK_TRY(gemv(ctx, 0, n, n, 1.0, dK, n, dc, 0.0, dyhat));                                          // yfitted = K c (full K)

@@ -78,6 +78,29 @@ try:
     raise AssertionError("a decomposition that fails the check against K twice must be an error")
 except L.BigKRLSError as e:
     assert e.code == L.EHIP and "the check against K" in str(e) and "also after the decomposition was redone" in str(e), str(e)
+# BIGKRLS_FAULT=eig_swap: two kept eigenvectors come back exchanged -- norms and eigenvalues right, the pairing wrong.
+# |Q r|^2 = k still holds, so only the comparison with K Q r sees it: on one GPU that half of the check is deferred to the
+# fit's single pass over K (marginal effects + fitted values + K [u_1 u_2]); the fit must then redo everything from the
+# decomposition on and return the undisturbed result; =eig_swap_always: an error.
+os.environ["BIGKRLS_FAULT"] = "eig_swap"
+before = ctx.counters()
+healed2 = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False)
+assert ctx.counters()["redone"] == before["redone"] + 1, (before, ctx.counters())
+assert healed2["lastkeeper"] == ref["lastkeeper"] and healed2["lambda"] == ref["lambda"]
+assert np.array_equal(healed2["coeffs"], ref["coeffs"]) and np.array_equal(healed2["derivatives"], ref["derivatives"])
+assert np.array_equal(healed2["yfitted"], ref["yfitted"])
+os.environ["BIGKRLS_FAULT"] = "eig_swap_always"
+try:
+    bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False)
+    raise AssertionError("a decomposition that fails the deferred check against K twice must be an error")
+except L.BigKRLSError as e:
+    assert e.code == L.EHIP and "the check against K" in str(e) and "also after the decomposition was redone" in str(e), str(e)
+# ... and without marginal effects the check is not deferred (its own product K [u_1 u_2]): caught and healed as well
+os.environ["BIGKRLS_FAULT"] = ""
+ref_nd = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False, derivative=False)
+os.environ["BIGKRLS_FAULT"] = "eig_swap"
+healed3 = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False, derivative=False)
+assert healed3["lambda"] == ref_nd["lambda"] and np.array_equal(healed3["coeffs"], ref_nd["coeffs"])
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)
