@@ -1,5 +1,5 @@
-# round 6, GPU calls 12 and 13: the fitted values out of the marginal-effects pass (no gemv over K of their own); call 13: the check of the decomposition against K rides along in that pass too -- tests, bench lines
-O=gpurun_out/${EVID:-r06o}; mkdir -p $O
+# round 6, GPU calls 12-14: fitted values and the check against K out of the marginal-effects pass; call 14: the O(N P) host loops of the fit on up to eight threads -- tests, bench lines
+O=gpurun_out/${EVID:-r06p}; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q --durations=5 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
