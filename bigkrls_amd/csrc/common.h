@@ -74,6 +74,9 @@ struct bigkrls_ctx {
   // pinned arena the small host -> device uploads of the divide & conquer go through (PinnedStage)
   char* h_stage = nullptr;
   int64_t h_stage_bytes = 0;
+  // host copy of the standardised X of the last fit (kept between fits: 40 MB at N = 100 000, P = 50, whose allocation
+  // and first touch cost milliseconds per call)
+  std::vector<double> h_xs;
   // ... and the small pinned buffer the group table of the stage-1 back-transform's precompute is uploaded from
   char* h_plan = nullptr;
   int64_t h_plan_bytes = 0;

@@ -303,7 +303,9 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   PhaseTimer timer(ctx);
   timer.mark();
   // ---- standardise (R/bigKRLS.R:248-254) straight into the pinned staging buffer, upload ----------
-  std::vector<double> Xs((size_t)(n * p)), ys((size_t)n);               // host copies for the O(NP) post-processing
+  std::vector<double>& Xs = ctx->h_xs;                                   // host copies for the O(NP) post-processing
+  if ((int64_t)Xs.size() < n * p) Xs.resize((size_t)(n * p));
+  std::vector<double> ys((size_t)n);
   for_columns(p, n, [&](int64_t j) {
     const double* x = h_X + j * n;
     double* xs = pin + j * n;
