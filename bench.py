@@ -707,9 +707,9 @@ def run(args, cfg, world, rank, local_rank, np, torch, dist):
                        "step (Neig << N, the reference's eigs_sym branch src/eigen.cpp:18-22)",
                        "achieved = 2 N^2 b flops (b = 128) per step / HIP-event duration on the launch stream, every "
                        "step bracketed; reads K once per step (8 N^2 B, AI = 32 flop/B)", stride=1),
-            mfma_entry("lanczos_cgs2", "gemm_kernel<T,N> + gemm_kernel<N,N>: classical Gram-Schmidt twice against all "
-                       "earlier blocks (C = B'W, W -= B C), four skinny GEMMs per step",
-                       "achieved = 8 N dim b flops per step / HIP-event duration, every step bracketed", stride=1),
+            mfma_entry("lanczos_cgs2", "gemm_kernel<T,N> + gemm_kernel<N,N>: classical Gram-Schmidt, first against the last "
+                       "two blocks, then against all of them (C = B'W, W -= B C), four skinny GEMMs per step",
+                       "achieved = 4 N (dim + 256) b flops per step / HIP-event duration, every step bracketed", stride=1),
         ]
         cands = [c for c in cands if c]
         # The two trailing-update entries are launches of ONE kernel (syrk_mirror_kernel<64>, one row in a rocprofv3

@@ -94,6 +94,10 @@ struct bigkrls_ctx {
   // input (a block recurrence that does not hold against K, non-finite entries after the tridiagonalisation); read and
   // cleared by the fit, which validated its input and redoes such a decomposition once (csrc/fit.hip)
   bool corrupt_run = false;
+  // set by the fit around a decomposition it is going to verify against K itself (ALL kept pairs, csrc/fit.hip): the
+  // block Lanczos then leaves out its own sample check of the last block of Ritz pairs against K (one more K-times-
+  // block product: 13 ms at N = 50 000, 50 ms at N = 100 000); not set for the redo after a failed check
+  bool caller_verifies = false;
   // device-side predicate of the next gemm() launches (kernel and split-K reduction return at once while *gemm_run_if
   // == 0): the T-factor chain of a stage-1 panel only runs when pq_chol left the panel to the Householder kernel
   const int* gemm_run_if = nullptr;

@@ -1962,6 +1962,7 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
   __syncthreads();
 #pragma unroll
   for (int ka = 0; ka < 8; ++ka) {
+#pragma unroll 1
     for (int kt = 0; kt < 16; ++kt) {
       const int k = 16 * ka + kt;
       double* rk = rowk[k & 1];
@@ -1982,10 +1983,12 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
 #pragma unroll
       for (int c = 0; c < 8; ++c) rj[c] = rk[tj + 16 * c] * rinv;
       if (tid < KRY_B && tid >= k) sR[k][tid] = rk[tid] * rinv;
+      // (entries in rows / columns <= k are dead: the tiles a < ka or c < ka, 60 % of the updates over the sweep, are
+      //  left alone -- ka is a compile-time constant of the unrolled outer loop)
 #pragma unroll
-      for (int a = 0; a < 8; ++a)
+      for (int a = ka; a < 8; ++a)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) t[a][c] = fma(-ri[a], rj[c], t[a][c]);   // (entries in rows / columns <= k are dead)
+        for (int c = ka; c < 8; ++c) t[a][c] = fma(-ri[a], rj[c], t[a][c]);
     }
   }
   __syncthreads();
@@ -1996,6 +1999,7 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
     for (int c = 0; c < 8; ++c) t[a][c] = (ti + 16 * a == tj + 16 * c) ? 1.0 : 0.0;
 #pragma unroll
   for (int ka = 7; ka >= 0; --ka) {
+#pragma unroll 1
     for (int kt = 15; kt >= 0; --kt) {
       const int k = 16 * ka + kt;
       double* rk = rowk[k & 1];
@@ -2013,10 +2017,11 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
       for (int a = 0; a < 8; ++a) f[a] = (ti + 16 * a < k) ? sR[ti + 16 * a][k] : 0.0;
 #pragma unroll
       for (int c = 0; c < 8; ++c) xk[c] = rk[tj + 16 * c];
+      // (f = 0 in the rows >= k, x_k = 0 in the columns < k: the tiles a > ka or c < ka would add -0 * x)
 #pragma unroll
-      for (int a = 0; a < 8; ++a)
+      for (int a = 0; a <= ka; ++a)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) t[a][c] = fma(-f[a], xk[c], t[a][c]);
+        for (int c = ka; c < 8; ++c) t[a][c] = fma(-f[a], xk[c], t[a][c]);
     }
   }
 #pragma unroll
@@ -2246,12 +2251,21 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_kb", 2.0 * (double)n * (double)n * b));
     BK_TRY(k_times(ctx, kop, n, Bj, b, W));
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_kb"));
-    if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_cgs2", 8.0 * (double)n * (double)dim * b));
+    // Two Gram-Schmidt passes where the projection cancels (the blocks of the three-term recurrence, B_{j-1} and B_j:
+    // |K B_j| shrinks to |beta_{j+1}|), one where it does not: with every earlier block kept orthogonal to rounding,
+    // K B_j has components of only eps |K| along B_0 ... B_{j-2}, which a single pass removes to rounding. So the
+    // first pass runs against the last two blocks only (256 of the dim columns), the second against all of them
+    // -- 4 n (dim + 256) b flops per step instead of 8 n dim b. BIGKRLS_KRY_CGS=2 (development): both passes against
+    // every block, as until round 6.
+    static const bool cgs_full = [] { const char* e = getenv("BIGKRLS_KRY_CGS"); return e && e[0] == '2'; }();
+    const int64_t loc0 = cgs_full ? 0 : (int64_t)std::max(0, steps - 1) * b;     // first column of the first pass
+    if (ctx->profile) BK_TRY(prof_begin(ctx, "lanczos_cgs2", 4.0 * (double)n * (double)(2 * dim - loc0) * b));
     for (int pass = 0; pass < 2; ++pass) {
-      BK_TRY(gram(B, dim, W, b, C));                       // (multi-GPU: local rows + one all-reduce of dim x 128)
-      if (pass == 0)   // A_j = B_j' K B_j: rows [steps b, steps b + b) of the first coefficient block
-        BK_TRY(copy_matrix(ctx, C + (int64_t)steps * b, b, b, dim, dAall + (int64_t)steps * b * b, b));
-      if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dim, -1.0, B + ro, n, C, dim, 1.0, W + ro, n));
+      const int64_t c0 = pass == 0 ? loc0 : 0, dimp = dim - c0;
+      BK_TRY(gram(B + c0 * n, dimp, W, b, C));             // (multi-GPU: local rows + one all-reduce of dimp x 128)
+      if (pass == 0)   // A_j = B_j' K B_j: the last b rows of the first coefficient block
+        BK_TRY(copy_matrix(ctx, C + ((int64_t)steps * b - c0), b, b, dimp, dAall + (int64_t)steps * b * b, b));
+      if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dimp, -1.0, B + c0 * n + ro, n, C, dimp, 1.0, W + ro, n));
     }
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_cgs2"));
     BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b, comm, ro, nr));   // synchronises the stream
@@ -2377,7 +2391,14 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     refine = rf && std::string(rf) == "1";
   }
   const double* dvals_final = nullptr;
-  if (!refine) {
+  if (!refine && ctx->caller_verifies && !getenv("BIGKRLS_KRY_SAMPLE")) {     // (the variable: A/B timing)
+    // the fit checks ALL kept pairs against K itself right after this call (two +-1 combinations, tighter than this
+    // sample's error threshold and as tight as its refinement threshold times sqrt(k)); if that fails, the decomposition
+    // is redone with the flag cleared, i.e. with the sample check and, where it asks for it, the refinement below
+    void* pT = nullptr;
+    BK_TRY(ws_get(ctx, SLOT_KRY_T, (dim * dim + dim) * sizeof(double), &pT));
+    dvals_final = (const double*)pT + dim * dim;
+  } else if (!refine) {
     const int64_t bs = std::min<int64_t>(k, b), c0 = k - bs;
     // theta of T sits at the head of SLOT_KRY_T's value vector (device): dvalsT of the last check
     void* pT = nullptr;
@@ -2456,6 +2477,14 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     const char* fault = getenv("BIGKRLS_FAULT");   // BIGKRLS_FAULT=vals_ulp: see the dense path
     if (fault && std::string(fault) == "vals_ulp" && nv > 1) {
       fault_nudge_ulp<<<1, 1, 0, st>>>(vals + nv / 2);
+      BK_HIP(hipGetLastError());
+    }
+    // BIGKRLS_FAULT=kry_swap: two kept Ritz vectors exchanged in the first call (see eig_swap in the dense path)
+    static int kswap_calls = 0;
+    const bool ks = fault && std::string(fault) == "kry_swap";
+    if (!ks) kswap_calls = 0;
+    if (ks && kswap_calls++ == 0 && nv > 3 && !comm) {
+      fault_swap_cols<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(vecs + (nv / 2) * ldv, vecs + (nv / 2 + 1) * ldv, (int)n);
       BK_HIP(hipGetLastError());
     }
   }

@@ -337,8 +337,13 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
     ctx->corrupt_run = false;
     return (rc != BIGKRLS_OK && corrupt) ? (int)BK_EWATCHDOG : rc;
   };
+  static const bool verify_on = [] { const char* e = getenv("BIGKRLS_VERIFY"); return !(e && e[0] == '0'); }();
+  bool first_try = true;      // cleared before any redo of the decomposition
   auto run_eigen = [&]() -> int {
   lastkeeper = 0;
+  // (the flag only concerns the block Lanczos: see common.h; every exit of this lambda goes through the guard)
+  struct Flag { bool& f; ~Flag() { f = false; } } flag_guard{ctx->caller_verifies};
+  ctx->caller_verifies = verify_on && first_try;
   if (!comm) {
     BK_TRY(soften(eigen(ctx, dK, n, n, neig, dvals, neig, eigtrunc, dQ, n, &lastkeeper)));
   } else if (dist_mode == DE_KRYLOV) {
@@ -462,10 +467,11 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   //     sqrt(k) and | |u|^2 - k | <= 1e-8 k, from one pass over K (rank-local rows in a multi-GPU fit), 8 N^2 bytes, and
   //     one over Q: 0.6 ms of a 410-ms fit at N = 20 000. (A sample of three pairs was not enough: a run whose
   //     eigenvalues were right to 1e-15 came back with c off by 4 % -- some columns of Q wrong, none of the three.)
-  // The block Lanczos (Neig << N) checks only the last block of its Ritz pairs against K itself (csrc/eigen.hip), i.e. a
-  // sample -- the kind of check that was not enough above: its pairs go through the same two combinations, at
-  // 1e-7 lambda_1 sqrt(k) (the iteration accepts true residuals up to 1e-9 lambda_1 per pair): one more pass over K,
-  // +4 ms at N = 50 000, rank-local rows in a multi-GPU fit.
+  // The block Lanczos (Neig << N) on its own checks only the last block of its Ritz pairs against K itself
+  // (csrc/eigen.hip), i.e. a sample -- the kind of check that was not enough above: in a fit its pairs go through the
+  // same two combinations at the same tolerance (the iteration stops at 1e-10 lambda_1 per pair), and the sample check
+  // -- a K-times-block product of 13 ms at N = 50 000, 50 ms at N = 100 000 -- is left out of the first attempt
+  // (ctx->caller_verifies); a redo runs with it, and with the Rayleigh-Ritz refinement where it asks for one.
   // BIGKRLS_VERIFY=0 switches the check off (A/B timing).
   // On one GPU with marginal effects asked for, the product K [u_1 u_2] is DEFERRED (round 6): the combinations ride
   // along in the one pass over K that step 4 makes anyway (marginal effects + fitted values), and the comparison happens
@@ -479,11 +485,15 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   std::vector<double> verify_l;                // host copy of L = Q (lambda o r), n x 2
   double verify_tol = 0.0;
   auto verify = [&]() -> int {
-    static const bool on = [] { const char* e = getenv("BIGKRLS_VERIFY"); return !(e && e[0] == '0'); }();
+    const bool on = verify_on;
     const bool krylov = neig < n && ((!comm && neig * 8 <= n && n >= 16384) || (comm && dist_mode == DE_KRYLOV));
     verify_pending = false;
     if (!on || lastkeeper <= 0) return BIGKRLS_OK;
-    const double vtol = krylov ? 1e-7 : 1e-8;
+    // (block Lanczos: the iteration stops at Ritz residuals of 1e-10 lambda_1 per pair, <= 1e-10 lambda_1 sqrt(k) for a
+    //  combination; its own sample check against K is left out in a first attempt -- ctx->caller_verifies -- so this
+    //  is the check of its pairs, at the tolerance of the dense path)
+    const double vtol = 1e-8;
+    (void)krylov;
     char buf[256];
     if (neig == n) {
       long double tr = 0.0L;
@@ -578,6 +588,7 @@ retry_from_eigen:
       if (getenv("BIGKRLS_VERBOSE") || getenv("BIGKRLS_REPORT_REDO"))
         fprintf(stderr, "[bigkrls] %s; redoing the decomposition\n", bigkrls_last_error());
       ctx->n_redone++;
+      first_try = false;
       continue;
     }
     if (has_nan() || lastkeeper <= 0) {
@@ -602,6 +613,7 @@ retry_from_eigen:
     if (getenv("BIGKRLS_VERBOSE") || getenv("BIGKRLS_REPORT_REDO"))
       fprintf(stderr, "[bigkrls] %s; redoing the decomposition\n", bigkrls_last_error());
     ctx->n_redone++;
+    first_try = false;
   }
   if (nan_agreed)
     return fail("Missing eigenvalues prevent bigKRLS from obtaining the regularization parameter lambda.\n\t"
@@ -710,6 +722,7 @@ retry_from_eigen:
           if (getenv("BIGKRLS_VERBOSE") || getenv("BIGKRLS_REPORT_REDO"))
             fprintf(stderr, "[bigkrls] %s; redoing the decomposition\n", bigkrls_last_error());
           deferred_redo_done = true;
+          first_try = false;
           ctx->n_redone++;
           timer.rewind(timer_n_before_eigen);
           goto retry_from_eigen;

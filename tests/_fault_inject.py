@@ -101,6 +101,23 @@ ref_nd = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False, derivative=Fal
 os.environ["BIGKRLS_FAULT"] = "eig_swap"
 healed3 = bk.bigKRLS(yf, Xf, ctx=ctx, eigtrunc=0.001, noisy=False, derivative=False)
 assert healed3["lambda"] == ref_nd["lambda"] and np.array_equal(healed3["coeffs"], ref_nd["coeffs"])
+# BIGKRLS_FAULT=kry_swap: the same with the block Lanczos as the fit's decomposition (Neig << N). Its own sample check
+# of the last block of Ritz pairs against K is left out of a fit's first attempt (the fit checks ALL kept pairs), so this
+# fault is seen by the fit's check only; the redo runs with the sample check and must return the undisturbed bits.
+Xk, yk = synth(16384, 5, 78)
+os.environ["BIGKRLS_FAULT"] = ""
+ref_k = bk.bigKRLS(yk, Xk, ctx=ctx, Neig=64, eigtrunc=0.001, noisy=False)
+for deriv in (True, False):
+    os.environ["BIGKRLS_FAULT"] = ""
+    ref_kd = ref_k if deriv else bk.bigKRLS(yk, Xk, ctx=ctx, Neig=64, eigtrunc=0.001, noisy=False, derivative=False)
+    os.environ["BIGKRLS_FAULT"] = "kry_swap"
+    before = ctx.counters()
+    healed_k = bk.bigKRLS(yk, Xk, ctx=ctx, Neig=64, eigtrunc=0.001, noisy=False, derivative=deriv)
+    assert ctx.counters()["redone"] == before["redone"] + 1, (deriv, before, ctx.counters())
+    assert healed_k["lastkeeper"] == ref_kd["lastkeeper"] and healed_k["lambda"] == ref_kd["lambda"]
+    assert np.array_equal(healed_k["coeffs"], ref_kd["coeffs"]) and np.array_equal(healed_k["yfitted"], ref_kd["yfitted"])
+    if deriv:
+        assert np.array_equal(healed_k["derivatives"], ref_k["derivatives"])
 os.environ["BIGKRLS_FAULT"] = "noconv"
 n2 = 16384                                                   # the size at which Lanczos is chosen by default
 X2, _ = synth(n2, p, 10)

@@ -408,6 +408,8 @@ def test_c5_fit_properties_which_derivatives(ctx, monkeypatch):
     from bigkrls_amd import ops
     from bigkrls_amd.synth import synth
     monkeypatch.delenv("BIGKRLS_EIGK", raising=False)
+    import gc
+    gc.collect()                           # (device outputs of the test before this one, kept alive by reference cycles)
     ctx.release_workspace()                # 258 of the 288 GB are needed: start from an empty device
     ctx.torch.cuda.empty_cache()
     n, p, neig = 100000, 50, 1024
