@@ -475,7 +475,9 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
     const int maxs = std::min(64, std::max(1, g.K / 256));
     // rough time model in us: a k-step of a workgroup ~0.06 us per unit of K; per split the partial
     // slab is written and read again (16 bytes per output element at ~5 TB/s) plus a fixed ~0.2 us
-    const double per_split = 3.2e-6 * (double)g.M * (double)g.N + 0.2;
+    // (measured for the block-Lanczos product, 391 tiles x K = 50 000: 5 splits 10.18 ms, 9 or 13 splits 9.98 ms,
+    //  tools/kb_shape_probe.hip -- for these long products the slab traffic costs half of what the model charged)
+    const double per_split = ((ntile >= 256 && g.K >= 16384) ? 1.6e-6 : 3.2e-6) * (double)g.M * (double)g.N + 0.2;
     double best = 1e30;
     constexpr int resident = 256 * gemm_occ<TA, TB, BN>();
     for (int sp = 1; sp <= maxs; ++sp) {
@@ -483,6 +485,11 @@ static int launch_gemm(bigkrls_ctx* ctx, const GemmOperands& g, double alpha, do
       const double cost = 0.06 * rounds * ((double)g.K / sp) + per_split * sp;
       if (cost < best - 1e-9) { best = cost; splits = sp; }
     }
+  }
+  {
+    // (development: BIGKRLS_GEMM_SPLITS=<n> overrides the count for products with K >= 16384, tools/kb_shape_probe.hip)
+    static const int env_splits = [] { const char* e = getenv("BIGKRLS_GEMM_SPLITS"); return e ? atoi(e) : 0; }();
+    if (env_splits > 0 && g.K >= 16384) splits = env_splits;
   }
   int k_chunk = ((g.K + splits - 1) / splits + BK - 1) / BK * BK;
   if (k_chunk < BK) k_chunk = BK;
