@@ -45,7 +45,10 @@
  * path and the block Lanczos (Neig << N) alike -- against K itself before using it
  * (trace when the whole spectrum is known; all kept pairs through two fixed +-1
  * combinations: |K Q r - Q Lambda r| and | |Q r|^2 - k |; one pass over K) and redo
- * it once; a second failure is BIGKRLS_EHIP. In a multi-GPU fit every rank then runs
+ * it once; a second failure is BIGKRLS_EHIP. (bigkrls_eigen with Neig << N checks the
+ * last block of its Ritz pairs against K itself; inside a fit that sample is left to
+ * the fit's check of all pairs in the first attempt and runs in a redo.) In a
+ * multi-GPU fit every rank then runs
  * the lambda search on rank 0's eigenvalues (one broadcast of 8 Neig bytes): the
  * ranks' branch sequences cannot diverge. bigkrls_ctx_get_counters() says how often
  * a context took one of these paths.
