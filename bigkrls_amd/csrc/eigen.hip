@@ -2057,6 +2057,38 @@ __global__ void kry_assemble_t(const double* __restrict__ Aall, const double* __
   }
 }
 
+// The projected matrix of the COMPRESSED basis [B Y (the k Ritz vectors of the check at s1 steps) | B_s1 ... B_{s2-1}]:
+//   [ diag(theta)   C'                         ]     C = beta_{s1} Y[last block rows, :]  (b x k)
+//   [ C             A_s1        beta_{s1+1}'   ]
+//   [               beta_{s1+1} A_{s1+1}   ... ]     dimension k + (s2 - s1) b
+__global__ void kry_assemble_compressed(const double* __restrict__ theta, const double* __restrict__ Cm, int k,
+                                        const double* __restrict__ Aall, const double* __restrict__ Ball, int s1, int s2,
+                                        int b, double* __restrict__ T) {
+  const int64_t m = (int64_t)k + (int64_t)(s2 - s1) * b, total = m * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e % m, c = e / m;
+    double v = 0.0;
+    if (r < k && c < k) {
+      v = (r == c) ? theta[r] : 0.0;
+    } else if (r >= k && c < k) {
+      if (r - k < b) v = Cm[(r - k) + c * b];
+    } else if (r < k) {
+      if (c - k < b) v = Cm[(c - k) + r * b];
+    } else {
+      const int jr = s1 + (int)((r - k) / b), jc = s1 + (int)((c - k) / b), lr = (int)((r - k) % b), lc = (int)((c - k) % b);
+      if (jr == jc) {
+        const double* Aj = Aall + (int64_t)jr * b * b;
+        v = 0.5 * (Aj[lr + (int64_t)lc * b] + Aj[lc + (int64_t)lr * b]);
+      } else if (jr == jc + 1) {
+        if (lr <= lc) v = Ball[(int64_t)jc * b * b + lr + (int64_t)lc * b];
+      } else if (jc == jr + 1) {
+        if (lc <= lr) v = Ball[(int64_t)jr * b * b + lc + (int64_t)lr * b];
+      }
+    }
+    T[e] = v;
+  }
+}
+
 // W (n x b, ld n) <- orthonormal basis of its columns by Cholesky QR, twice; Rout (host, b x b upper)
 // gets the triangular factor with W_in = W_out Rout. tmp is an n x b scratch, dG holds 4 b^2 doubles
 // and an int. Everything runs on the device (Gram matrix, factorisation and inverse in one workgroup,
@@ -2192,7 +2224,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     int rc = ws_get(ctx, SLOT_KRY_B, n * maxdim * sizeof(double), &pB);
     if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_W, 2 * n * (int64_t)std::max<int64_t>(b, k) * sizeof(double), &pW);
     if (rc == BIGKRLS_OK)
-      rc = ws_get(ctx, SLOT_KRY_C, (maxdim * b + 5 * b * b + 8 + k * k + 2 * k + 2 * (int64_t)maxsteps * b * b) *
+      rc = ws_get(ctx, SLOT_KRY_C, (maxdim * b + 5 * b * b + 8 + k * k + 2 * k + 2 * (int64_t)maxsteps * b * b + k + b * k) *
                                        sizeof(double), &pC);
     if (rc == BIGKRLS_OK && kop.comm)   // the staging of the per-step all-gather, before the first one is entered
       rc = ws_get(ctx, SLOT_COMM_STAGE, (int64_t)(kop.comm->nranks + 1) * kop.nb * std::max<int64_t>(b, k) * sizeof(double), &pC2);
@@ -2217,6 +2249,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   // diagonal blocks A_j and sub-diagonal factors beta_{j+1} of the projected matrix stay on the device
   double* dAall = dA + b * b + k * k + 2 * k;
   double* dBall = dAall + (int64_t)maxsteps * b * b;
+  double* dPrev = dBall + (int64_t)maxsteps * b * b;   // [theta (k) | C (b x k)] of the last full check (for the estimate)
   std::vector<double> Rtmp;                        // beta of the last step (host copy, for the Ritz residuals)
   bool breakdown = false;
   // ---- B_0 ----------------------------------------------------------------------------------
@@ -2231,7 +2264,9 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   BK_HIP(hipMemcpyAsync(B, W, n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
   int steps = 0;
   int64_t dim = b;
-  std::vector<double> theta;       // Ritz values of the last check (descending)
+  std::vector<double> theta;       // Ritz values of the last full check (descending)
+  int full_steps = 0;              // steps of the last full check (0: none yet)
+  bool next_is_estimate = false;   // the next check decomposes the compressed projected problem (see below)
   void* pY = nullptr;
   bool converged = false;
   // each check is a dense eigensolve of T (latency-bound, ~12 us per row of T); the first one comes at a
@@ -2279,81 +2314,153 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     // ---- convergence check on the projected problem ---------------------------------------------
     if (last || steps >= next_check) {
       const int64_t m = (int64_t)steps * b;
-      void *pT = nullptr;
-      {
-        int rc = ws_get(ctx, SLOT_KRY_T, (m * m + m) * sizeof(double), &pT);
-        if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_Y, m * k * sizeof(double), &pY);
-        BK_TRY(kry_agree_status(kop, rc));
-      }
-      double* dT = (double*)pT;
-      double* dvalsT = dT + m * m;
-      hipLaunchKernelGGL(kry_assemble_t, dim3((unsigned)std::min<int64_t>((m * m + 255) / 256, 8192)), dim3(256), 0, st,
-                         (const double*)dAall, (const double*)dBall, steps, b, dT);
-      BK_CHECK_LAUNCH();
-      int64_t nvY = 0;
-      // (replicated, but after a fault one rank's copy may fail where its peers' do not: agreed, so nobody leaves alone)
-      BK_TRY(kry_agree_status(kop, eigen(ctx, dT, m, m, m, dvalsT, k, -1.0, (double*)pY, m, &nvY, 0, 1, EIG_FULL)));
-      // theta (m values) and the last b rows of Y come down through the context's pinned buffer
-      double* hp = nullptr;
-      BK_TRY(pinned_get(ctx, m + (int64_t)b * k, &hp));
-      theta.resize(m);
-      double worst = 0.0, worst_kept = 0.0;
-      int64_t n_conv = 0;   // Ritz pairs below the tolerance
-      std::vector<double> Ylast((size_t)b * k);
-      {
-        BK_HIP(hipMemcpyAsync(hp, dvalsT, m * sizeof(double), hipMemcpyDeviceToHost, st));
-        BK_HIP(hipMemcpy2DAsync(hp + m, b * sizeof(double), (double*)pY + (m - b), m * sizeof(double),
-                                b * sizeof(double), k, hipMemcpyDeviceToHost, st));
-        BK_HIP(hipStreamSynchronize(st));
-        std::memcpy(theta.data(), hp, (size_t)m * sizeof(double));
-        std::memcpy(Ylast.data(), hp + m, (size_t)b * k * sizeof(double));
-      }
-      if (!breakdown) {
-        // residual of Ritz pair i: | beta_m * y_i[last block] |
-        const std::vector<double>& beta = Rtmp;
+      const std::vector<double>& beta = Rtmp;       // T[steps, steps - 1]: couples the last block to the next one
+      // residuals |beta y_i[last block]| of the first k Ritz pairs of a projected problem whose eigenvectors end in the
+      // b rows ylast (b x k, host)
+      struct Resid { double worst = 0.0, worst_kept = 0.0; int64_t n_conv = 0; };
+      auto residuals = [&](const double* th, const double* ylast) {
+        Resid r;
+        if (breakdown) return r;
         for (int64_t i = 0; i < k; ++i) {
           double r2 = 0.0;
-          for (int r = 0; r < b; ++r) {
+          for (int rr = 0; rr < b; ++rr) {
             double sacc = 0.0;
-            for (int c = r; c < b; ++c) sacc += beta[r + (size_t)c * b] * Ylast[c + (size_t)i * b];
+            for (int c = rr; c < b; ++c) sacc += beta[rr + (size_t)c * b] * ylast[c + (size_t)i * b];
             r2 += sacc * sacc;
           }
-          worst = std::max(worst, std::sqrt(r2));
-          if (std::sqrt(r2) <= tol * std::fabs(theta[0])) ++n_conv;
-          if (keep_thresh >= 0.0 && theta[i] >= keep_thresh * theta[0]) worst_kept = std::max(worst_kept, std::sqrt(r2));
+          r.worst = std::max(r.worst, std::sqrt(r2));
+          if (std::sqrt(r2) <= tol * std::fabs(th[0])) ++r.n_conv;
+          if (keep_thresh >= 0.0 && th[i] >= keep_thresh * th[0]) r.worst_kept = std::max(r.worst_kept, std::sqrt(r2));
         }
-      }
-      double theta1 = std::fabs(theta[0]);
-      {
+        return r;
+      };
+      // the m x m projected matrix (estimate == false), or the compressed one of the estimate (below), is decomposed by the
+      // dense path; theta (mm values) and the last b rows of Y come down through the context's pinned buffer
+      std::vector<double> Ylast((size_t)b * k), th;
+      auto solve_projected = [&](double* dT, int64_t mm, double* dvalsT) -> int {
+        int64_t nvY = 0;
+        // (replicated, but after a fault one rank's copy may fail where its peers' do not: agreed, so nobody leaves alone)
+        BK_TRY(kry_agree_status(kop, eigen(ctx, dT, mm, mm, mm, dvalsT, k, -1.0, (double*)pY, mm, &nvY, 0, 1, EIG_FULL)));
+        double* hp = nullptr;
+        BK_TRY(pinned_get(ctx, mm + (int64_t)b * k, &hp));
+        BK_HIP(hipMemcpyAsync(hp, dvalsT, mm * sizeof(double), hipMemcpyDeviceToHost, st));
+        BK_HIP(hipMemcpy2DAsync(hp + mm, b * sizeof(double), (double*)pY + (mm - b), mm * sizeof(double),
+                                b * sizeof(double), k, hipMemcpyDeviceToHost, st));
+        BK_HIP(hipStreamSynchronize(st));
+        th.assign(hp, hp + mm);
+        std::memcpy(Ylast.data(), hp + mm, (size_t)b * k * sizeof(double));
+        return BIGKRLS_OK;
+      };
+      auto agree_worst = [&](double& worst, double& theta1) -> int {
         double ag[2] = {-worst, theta1};     // the largest residual and the smallest theta_1 over the ranks
         BK_TRY(kry_agree_min(kop, ag, 2));
         worst = -ag[0];
         theta1 = ag[1];
-      }
-      if (getenv("BIGKRLS_VERBOSE"))
-        fprintf(stderr, "[bigkrls] block Lanczos check: steps=%d worst=%.3e worst(kept)=%.3e converged=%lld of %lld theta0=%.4e\n",
-                steps, worst, worst_kept, (long long)n_conv, (long long)k, theta[0]);
-      {
-        char buf[160];
-        snprintf(buf, sizeof buf, " [check steps=%d worst=%.3e theta0=%.6e breakdown=%d]", steps, worst, theta[0], (int)breakdown);
-        kry_diag += buf;
-      }
-      if (worst <= tol * theta1 || last) {
-        converged = worst <= tol * theta1;
-        dim = m;
-        break;
-      }
+        return BIGKRLS_OK;
+      };
       // Next check. The history of the worst residual is a plateau (O(1) while the subspace does not reach the
       // k-th eigenvalue yet) followed by a collapse at a steady x25 - x45 per step (measured: N = 100 000,
       // k = 1024: 2.6e-2, 6.0e-4, 1.4e-5, 3.1e-7; N = 50 000, k = 512: 6.0e-4, 3.5e-5, 1.4e-6, 6.1e-8), so a rate
       // fitted to two plateau samples overshoots by many steps. The distance to the tolerance at an assumed
       // collapse rate is used instead: an optimistic rate where a check (a dense eigensolve of T, ~12 us per
       // row) is cheaper than a step (2 n^2 b flops), so undershooting costs little, a cautious one otherwise.
-      const double gain = check_is_cheap ? 40.0 : 15.0;
-      int inc = (worst > 0.0) ? (int)std::ceil(std::log(worst / (tol * theta1)) / std::log(gain)) : 1;
-      inc = std::max(1, std::min(inc, std::max(2, steps / 2)));
-      next_check = steps + inc;
-      if (getenv("BIGKRLS_KRY_CHECK_EVERY")) next_check = steps + 1;   // (development: the convergence history)
+      auto steps_to_go = [&](double worst, double theta1) {
+        const double gain = check_is_cheap ? 40.0 : 15.0;
+        int inc = (worst > 0.0) ? (int)std::ceil(std::log(worst / (tol * theta1)) / std::log(gain)) : 1;
+        return std::max(1, std::min(inc, std::max(2, steps / 2)));
+      };
+      // ---- an ESTIMATE instead of the full check (round 6): where the last full check (at full_steps) put the end of
+      // the iteration four or more steps away -- a forecast made from the plateau, which the check at its end only
+      // ever corrected (C4: 20 -> 25 -> 27) -- the check at that point decomposes the COMPRESSED projected problem:
+      // the k Ritz vectors of the last full check plus the blocks since, dimension k + 128 d instead of 128 steps
+      // (C4, step 25: 1 152 instead of 3 200). The Lanczos relation holds exactly for that basis, so its residuals are
+      // true residuals and track the full check's within a factor of two; the directions dropped at the compression
+      // never come back, so it cannot replace the full check (its converged set can miss wanted eigenvalues,
+      // tools/experiments/DEAD_ENDS.md): it only says where the next FULL check goes, and a full check follows at
+      // once should it report convergence.
+      bool full = true;
+      const int64_t mc = k + (int64_t)(steps - full_steps) * b;
+      if (next_is_estimate && !last && full_steps > 0 && 2 * mc <= m && !getenv("BIGKRLS_KRY_NOEST")) {
+        void* pT = nullptr;
+        {
+          int rc = ws_get(ctx, SLOT_KRY_T, (mc * mc + mc) * sizeof(double), &pT);
+          if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_Y, mc * k * sizeof(double), &pY);
+          BK_TRY(kry_agree_status(kop, rc));
+        }
+        double* dT = (double*)pT;
+        hipLaunchKernelGGL(kry_assemble_compressed, dim3((unsigned)std::min<int64_t>((mc * mc + 255) / 256, 8192)), dim3(256), 0,
+                           st, (const double*)dPrev, (const double*)(dPrev + k), (int)k, (const double*)dAall,
+                           (const double*)dBall, full_steps, steps, b, dT);
+        BK_CHECK_LAUNCH();
+        BK_TRY(solve_projected(dT, mc, dT + mc * mc));
+        Resid r = residuals(th.data(), Ylast.data());
+        double worst = r.worst, theta1 = std::fabs(th[0]);
+        BK_TRY(agree_worst(worst, theta1));
+        if (getenv("BIGKRLS_VERBOSE"))
+          fprintf(stderr, "[bigkrls] block Lanczos estimate: steps=%d (compressed from %d: %lld instead of %lld) worst=%.3e converged=%lld of %lld theta0=%.4e\n",
+                  steps, full_steps, (long long)mc, (long long)m, worst, (long long)r.n_conv, (long long)k, th[0]);
+        {
+          char buf[160];
+          snprintf(buf, sizeof buf, " [estimate steps=%d worst=%.3e theta0=%.6e]", steps, worst, th[0]);
+          kry_diag += buf;
+        }
+        next_is_estimate = false;            // (what follows an estimate is a full check)
+        if (!(worst <= tol * theta1)) {
+          full = false;
+          next_check = steps + steps_to_go(worst, theta1);
+        }
+      }
+      if (full) {
+        void *pT = nullptr;
+        {
+          int rc = ws_get(ctx, SLOT_KRY_T, (m * m + m) * sizeof(double), &pT);
+          if (rc == BIGKRLS_OK) rc = ws_get(ctx, SLOT_KRY_Y, m * k * sizeof(double), &pY);
+          BK_TRY(kry_agree_status(kop, rc));
+        }
+        double* dT = (double*)pT;
+        double* dvalsT = dT + m * m;
+        hipLaunchKernelGGL(kry_assemble_t, dim3((unsigned)std::min<int64_t>((m * m + 255) / 256, 8192)), dim3(256), 0, st,
+                           (const double*)dAall, (const double*)dBall, steps, b, dT);
+        BK_CHECK_LAUNCH();
+        BK_TRY(solve_projected(dT, m, dvalsT));
+        theta = th;
+        Resid r = residuals(theta.data(), Ylast.data());
+        double worst = r.worst, theta1 = std::fabs(theta[0]);
+        BK_TRY(agree_worst(worst, theta1));
+        if (getenv("BIGKRLS_VERBOSE"))
+          fprintf(stderr, "[bigkrls] block Lanczos check: steps=%d worst=%.3e worst(kept)=%.3e converged=%lld of %lld theta0=%.4e\n",
+                  steps, worst, r.worst_kept, (long long)r.n_conv, (long long)k, theta[0]);
+        {
+          char buf[160];
+          snprintf(buf, sizeof buf, " [check steps=%d worst=%.3e theta0=%.6e breakdown=%d]", steps, worst, theta[0], (int)breakdown);
+          kry_diag += buf;
+        }
+        if (worst <= tol * theta1 || last) {
+          converged = worst <= tol * theta1;
+          dim = m;
+          break;
+        }
+        const int inc = steps_to_go(worst, theta1);
+        next_check = steps + inc;
+        // what the estimate at next_check needs of this check: the k Ritz values and C = beta Y[last block rows, :]
+        // (b x k), the coupling of the Ritz vectors to the next block -- kept on the device behind the blocks of T
+        next_is_estimate = inc >= 4;
+        full_steps = steps;
+        if (next_is_estimate) {
+          double* hp = nullptr;
+          BK_TRY(pinned_get(ctx, k + (int64_t)b * k, &hp));
+          for (int64_t i = 0; i < k; ++i) hp[i] = theta[i];
+          for (int64_t i = 0; i < k; ++i)
+            for (int rr = 0; rr < b; ++rr) {
+              double sacc = 0.0;
+              for (int c = rr; c < b; ++c) sacc += beta[rr + (size_t)c * b] * Ylast[c + (size_t)i * b];
+              hp[k + rr + i * b] = sacc;
+            }
+          BK_HIP(hipMemcpyAsync(dPrev, hp, (size_t)(k + (int64_t)b * k) * sizeof(double), hipMemcpyHostToDevice, st));
+          BK_HIP(hipStreamSynchronize(st));     // (the pinned buffer is the eigensolver's as well)
+        }
+      }
+      if (getenv("BIGKRLS_KRY_CHECK_EVERY")) { next_check = steps + 1; next_is_estimate = false; }   // (development: the convergence history)
     }
     BK_HIP(hipMemcpyAsync(B + (int64_t)steps * b * n, W, n * b * sizeof(double), hipMemcpyDeviceToDevice, st));
     dim = (int64_t)(steps + 1) * b;

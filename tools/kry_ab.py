@@ -10,6 +10,7 @@ rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     ("default", {}),
+    ("full_checks_only", {"BIGKRLS_KRY_NOEST": "1"}),
     ("cgs_twice_against_all", {"BIGKRLS_KRY_CGS": "2"}),
     ("with_sample_check", {"BIGKRLS_KRY_SAMPLE": "1"}),
     ("round5_behaviour", {"BIGKRLS_KRY_CGS": "2", "BIGKRLS_KRY_SAMPLE": "1"}),

@@ -1,0 +1,14 @@
+# round 6, GPU call 18: the estimate on the compressed projected problem in place of the block Lanczos' middle check
+O=gpurun_out/${EVID:-r06t}; mkdir -p $O
+export TMPDIR=/tmp
+BIGKRLS_VERBOSE=1 python tools/kry_history.py 50000 20 512 104 2>&1 | grep -i "lanczos" > $O/kry_verbose_C4.log; cat $O/kry_verbose_C4.log
+BIGKRLS_VERBOSE=1 python tools/kry_history.py 100000 50 1024 105 2>&1 | grep -i "lanczos" > $O/kry_verbose_C5.log; cat $O/kry_verbose_C5.log
+BIGKRLS_VERBOSE=1 python tools/kry_history.py 30000 8 256 7 2>&1 | grep -i "lanczos" > $O/kry_verbose_30000.log; cat $O/kry_verbose_30000.log
+python tools/kry_ab.py 50000 20 512 2 2>&1 | grep -v amdgpu.ids > $O/kry_ab_C4.log; cat $O/kry_ab_C4.log
+python -m pytest tests -m gpu -q --durations=5 > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+tail -4 $O/gpu_tests.log; tail -2 $O/smoke.log
+for c in C4 C5; do python bench.py --config $c --steps 4 --warmup 2 --no-cpu-baseline 2>$O/bench_$c.err | tail -1 > $O/bench_$c.json; done
+for f in $O/bench_*.json; do python -c "
+import json
+d=json.load(open('$f')); r=d['roofline']; print('$f', d['value'], r.get('frac'), r.get('fit_frac'), d['phases_s'])"; done
