@@ -241,7 +241,8 @@ def _compact_entry(e):
 
 
 TRAFFIC_SOURCE = ("model: algorithmic bytes x the (FETCH_SIZE+WRITE_SIZE)/algorithmic ratio of separate rocprofv3 --pmc "
-                  "passes (profiles/r05/r05u_syrk_traffic_pmc.json, r03/, r02/, r04/), not a counter read in this run")
+                  "passes (profiles/r03/, r02/, r04/ per launch shape; cross-checked over all in-fit launches: "
+                  "profiles/r06/r06z_syrk_infit_traffic_pmc.json, 1.066), not a counter read in this run")
 
 
 def compact_line(res):

@@ -486,14 +486,12 @@ static int fit_impl(bigkrls_ctx* ctx, bigkrls_comm* comm, const double* h_X, con
   double verify_tol = 0.0;
   auto verify = [&]() -> int {
     const bool on = verify_on;
-    const bool krylov = neig < n && ((!comm && neig * 8 <= n && n >= 16384) || (comm && dist_mode == DE_KRYLOV));
     verify_pending = false;
     if (!on || lastkeeper <= 0) return BIGKRLS_OK;
     // (block Lanczos: the iteration stops at Ritz residuals of 1e-10 lambda_1 per pair, <= 1e-10 lambda_1 sqrt(k) for a
     //  combination; its own sample check against K is left out in a first attempt -- ctx->caller_verifies -- so this
     //  is the check of its pairs, at the tolerance of the dense path)
     const double vtol = 1e-8;
-    (void)krylov;
     char buf[256];
     if (neig == n) {
       long double tr = 0.0L;
