@@ -1938,7 +1938,7 @@ __global__ __launch_bounds__(256) void kry_resid_sq_kernel(const double* __restr
 // diagonal), inv(R) overwrites G. *flag is set when a pivot is not positive (breakdown).
 constexpr int KRY_B = 128;
 __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ G, int b, double* __restrict__ Rout,
-                                                            int* __restrict__ flag) {
+                                                            int* __restrict__ flag, double* __restrict__ stats) {
   // Register tiles: thread (ti, tj) of a 16 x 16 grid owns the entries (ti + 16 a, tj + 16 c), a, c = 0..7 (cyclic, so
   // that the shrinking active part stays spread over all threads). Both phases are 128 rank-1 steps with ONE barrier
   // each: the owners of row k publish it through a double-buffered LDS vector, everybody updates its 8 x 8 tile.
@@ -1959,6 +1959,12 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
       t[a][c] = (i < b && j < b) ? 0.5 * (G[i + (int64_t)j * b] + G[j + (int64_t)i * b]) : (i == j ? 1.0 : 0.0);
     }
   for (int e = tid; e < KRY_B * (KRY_B + 1); e += 256) (&sR[0][0])[e] = 0.0;
+  double dmin = 1e300, dmax = 0.0;
+  if (tid == 0) {                 // trace(G) = |W|_F^2: bounds every residual |W y| when the factorisation breaks down
+    double tr = 0.0;
+    for (int i = 0; i < b; ++i) tr += G[i + (int64_t)i * b];
+    stats[2] = tr;
+  }
   __syncthreads();
 #pragma unroll
   for (int ka = 0; ka < 8; ++ka) {
@@ -1972,8 +1978,16 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
       }
       __syncthreads();
       const double d = rk[k];
+      if (k < b) {                        // (the pivots: squared norms of the columns orthogonalised so far; uniform)
+        dmin = d < dmin ? d : dmin;
+        dmax = d > dmax ? d : dmax;
+      }
       if (!(d > 0.0) || !isfinite(d)) {   // uniform
-        if (tid == 0) *flag = 1;
+        if (tid == 0) {
+          *flag = 1;
+          stats[0] = dmin;
+          stats[1] = dmax;
+        }
         return;
       }
       const double rinv = 1.0 / sqrt(d);
@@ -1990,6 +2004,10 @@ __global__ __launch_bounds__(256) void kry_chol_inv_kernel(double* __restrict__ 
 #pragma unroll
         for (int c = ka; c < 8; ++c) t[a][c] = fma(-ri[a], rj[c], t[a][c]);
     }
+  }
+  if (tid == 0) {
+    stats[0] = dmin;
+    stats[1] = dmax;
   }
   __syncthreads();
   // ---- X = inv(R) ------------------------------------------------------------------------------------
@@ -2098,7 +2116,7 @@ __global__ void kry_assemble_compressed(const double* __restrict__ theta, const 
 // kernel: identical factors on every rank) and W_loc R^-1 is local -- CholeskyQR2 in its communication-avoiding form.
 int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, double* dG,
                std::vector<double>& Rout, bool* breakdown, double* dRkeep = nullptr, bigkrls_comm* comm = nullptr,
-               int64_t ro = 0, int64_t nr = -1) {
+               int64_t ro = 0, int64_t nr = -1, double* pivots = nullptr) {
   hipStream_t st = ctx->stream;
   BK_REQUIRE(b <= KRY_B, "kry_cholqr: block too wide");
   if (nr < 0) nr = n;
@@ -2107,12 +2125,14 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
   double* dRacc = dR2 + (int64_t)b * b;
   int* dflag = (int*)(dRacc + (int64_t)b * b);
   *breakdown = false;
-  BK_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
+  BK_HIP(hipMemsetAsync(dflag, 0, 7 * sizeof(double), st));
   for (int pass = 0; pass < 2; ++pass) {
     if (nr > 0) BK_TRY(gemm(ctx, 1, 0, b, b, nr, 1.0, *W + ro, n, *W + ro, n, 0.0, dG, b));
     else BK_HIP(hipMemsetAsync(dG, 0, (size_t)b * b * sizeof(double), st));
     if (comm) BK_TRY(comm_all_reduce(comm, dG, (int64_t)b * b, COMM_SUM));
-    hipLaunchKernelGGL(kry_chol_inv_kernel, dim3(1), dim3(256), 0, st, dG, b, pass == 0 ? dR1 : dR2, dflag);
+    // (behind the flag: [flag | smallest pivot, largest pivot, trace of the Gram matrix: pass 0 | the same: pass 1])
+    hipLaunchKernelGGL(kry_chol_inv_kernel, dim3(1), dim3(256), 0, st, dG, b, pass == 0 ? dR1 : dR2, dflag,
+                       (double*)dflag + 1 + 3 * pass);
     BK_CHECK_LAUNCH();
     if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, b, 1.0, *W + ro, n, dG, b, 0.0, *tmp + ro, n));
     std::swap(*W, *tmp);
@@ -2123,11 +2143,12 @@ int kry_cholqr(bigkrls_ctx* ctx, double** W, double** tmp, int64_t n, int b, dou
   // context's pinned buffer
   double* hp = nullptr;
   BK_TRY(pinned_get(ctx, (int64_t)b * b + 8, &hp));
-  BK_HIP(hipMemcpyAsync(hp, dRacc, ((size_t)b * b + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+  BK_HIP(hipMemcpyAsync(hp, dRacc, ((size_t)b * b + 7) * sizeof(double), hipMemcpyDeviceToHost, st));
   BK_HIP(hipStreamSynchronize(st));
   Rout.assign(hp, hp + (size_t)b * b);
   int h_flag = 0;
   std::memcpy(&h_flag, hp + (size_t)b * b, sizeof(int));
+  if (pivots) std::memcpy(pivots, hp + (size_t)b * b + 1, 6 * sizeof(double));
   if (h_flag != 0) *breakdown = true;   // (W then holds garbage; the caller stops with the blocks it has)
   return BIGKRLS_OK;
 }
@@ -2265,6 +2286,9 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   int steps = 0;
   int64_t dim = b;
   std::vector<double> theta;       // Ritz values of the last full check (descending)
+  double wnorm_sq = 0.0;           // |W|_F^2 of the block the last step produced (before its QR)
+  double wmax_seen = 0.0;          // the largest direction any new block had (square root of the largest Gram pivot)
+  bool early_check_done = false;   // the check ahead of the schedule on a (numerically) invariant Krylov space, see below
   int full_steps = 0;              // steps of the last full check (0: none yet)
   bool next_is_estimate = false;   // the next check decomposes the compressed projected problem (see below)
   void* pY = nullptr;
@@ -2303,7 +2327,54 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
       if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dimp, -1.0, B + c0 * n + ro, n, C, dimp, 1.0, W + ro, n));
     }
     if (ctx->profile) BK_TRY(prof_end(ctx, "lanczos_cgs2"));
-    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b, comm, ro, nr));   // synchronises the stream
+    // piv: smallest / largest pivot and trace of the Gram matrix W'W, first and second pass of the Cholesky QR (the
+    // same on every rank: the Gram matrices are all-reduced)
+    double piv[6] = {0, 0, 0, 0, 0, 0};
+    BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rtmp, &breakdown, dBall + (int64_t)steps * b * b, comm, ro, nr, piv));   // synchronises the stream
+    if (getenv("BIGKRLS_KRY_PIVOTS"))    // (development: how well conditioned the new block was)
+      fprintf(stderr, "[bigkrls] block Lanczos step %d: Gram pivots %.3e ... %.3e (ratio %.1e), second pass %.3e ... %.3e%s\n", steps,
+              piv[0], piv[1], piv[1] > 0 ? piv[0] / piv[1] : 0.0, piv[3], piv[4], breakdown ? "  BREAKDOWN" : "");
+    wnorm_sq = piv[2];
+    // An ill-conditioned new block (cond(W) ~ sqrt(largest / smallest pivot) above 1e4): W was orthogonal to the
+    // earlier blocks to eps |W|, but its smallest directions were scaled up by the QR, and with them what they had
+    // left along the earlier blocks -- eps cond(W). One more Gram-Schmidt pass of the (now orthonormal) block
+    // against all blocks and one more Cholesky QR; beta takes the third factor. What the pass removes from the block
+    // recurrence is of the size of the rounding of W itself. (Numerically low-rank kernels: P = 2, 3.)
+    if (!breakdown && piv[1] > 0.0 && piv[0] < 1e-8 * piv[1]) {
+      BK_TRY(gram(B, dim, W, b, C));
+      if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dim, -1.0, B + ro, n, C, dim, 1.0, W + ro, n));
+      std::vector<double> R3, prev(Rtmp);
+      bool bd3 = false;
+      BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, R3, &bd3, nullptr, comm, ro, nr));
+      if (bd3) {
+        breakdown = true;
+      } else {
+        for (int c = 0; c < b; ++c)          // beta = R3 beta (both upper triangular)
+          for (int r = 0; r <= c; ++r) {
+            double acc = 0.0;
+            for (int t = r; t <= c; ++t) acc += R3[r + (size_t)t * b] * prev[t + (size_t)c * b];
+            Rtmp[r + (size_t)c * b] = acc;
+          }
+        double* hp = nullptr;
+        BK_TRY(pinned_get(ctx, (int64_t)b * b, &hp));
+        std::memcpy(hp, Rtmp.data(), (size_t)b * b * sizeof(double));
+        BK_HIP(hipMemcpyAsync(dBall + (int64_t)steps * b * b, hp, (size_t)b * b * sizeof(double), hipMemcpyHostToDevice, st));
+        BK_HIP(hipStreamSynchronize(st));
+        if (getenv("BIGKRLS_VERBOSE")) fprintf(stderr, "[bigkrls] block Lanczos step %d: ill-conditioned block (pivot ratio %.1e) re-orthogonalised\n", steps, piv[0] / piv[1]);
+      }
+    }
+    // The Krylov space is invariant to working precision when the new block is nothing but rounding: its largest
+    // direction a millionth of the largest one any block had. Going on would normalise noise into unit vectors for
+    // step after step until a pivot turns negative (P = 2: ten such steps before the first scheduled check); the
+    // check comes now instead, as soon as the subspace has k columns, and decides with the true residuals.
+    {
+      const double wmax = std::sqrt(std::max(piv[1], 0.0));
+      if (!breakdown && !early_check_done && wmax <= 1e-6 * wmax_seen && (int64_t)(steps + 1) * b >= k) {
+        next_check = std::min(next_check, steps + 1);      // (once: the checks after it follow their own forecasts)
+        early_check_done = true;
+      }
+      wmax_seen = std::max(wmax_seen, wmax);
+    }
     ++steps;
     {
       double okv = breakdown ? 0.0 : 1.0;
@@ -2320,7 +2391,13 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
       struct Resid { double worst = 0.0, worst_kept = 0.0; int64_t n_conv = 0; };
       auto residuals = [&](const double* th, const double* ylast) {
         Resid r;
-        if (breakdown) return r;
+        if (breakdown) {
+          // the factor beta of the last block does not exist (its Gram matrix is not positive definite): every
+          // residual |W y| is bounded by |W|_F -- zero to working precision when the Krylov space is invariant, which
+          // is the breakdown that means convergence; anything else is reported as not converged (dense path)
+          r.worst = r.worst_kept = std::sqrt(std::max(wnorm_sq, 0.0));
+          return r;
+        }
         for (int64_t i = 0; i < k; ++i) {
           double r2 = 0.0;
           for (int rr = 0; rr < b; ++rr) {
@@ -2378,6 +2455,10 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
       // never come back, so it cannot replace the full check (its converged set can miss wanted eigenvalues,
       // tools/experiments/DEAD_ENDS.md): it only says where the next FULL check goes, and a full check follows at
       // once should it report convergence.
+      if (m < k) {      // (a breakdown before the subspace had k columns: nothing to decompose -- the dense path)
+        dim = m;
+        break;
+      }
       bool full = true;
       const int64_t mc = k + (int64_t)(steps - full_steps) * b;
       if (next_is_estimate && !last && full_steps > 0 && 2 * mc <= m && !getenv("BIGKRLS_KRY_NOEST")) {

@@ -438,6 +438,43 @@ def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, ne
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p,neig", [(2, 512), (3, 384), (1, 256)])
+def test_eigen_block_lanczos_on_numerically_low_rank_kernels(lib, monkeypatch, p, neig):
+    """Kernels of one to three columns fall below rounding long before Neig eigenvalues (numerical rank ~20 / ~150 /
+    ~600 at N = 17 000): the block Krylov space becomes invariant to working precision after a few steps. The library's
+    default choice (N >= 16384, Neig <= N/8: block Lanczos) must then stop and decide on true residuals instead of
+    normalising rounding noise into basis vectors (P = 2, 3), re-orthogonalise the ill-conditioned blocks on the way,
+    and hand a breakdown before the subspace has Neig columns to the dense path (P = 1) -- the same pairs as the dense
+    path in every case (the reference's eigs_sym branch has no such restriction, src/eigen.cpp:18-22)."""
+    import bigkrls_amd as bk
+    from bigkrls_amd import ops
+    ctx = bk.Context(0)
+    n = 17000
+    X, y = orc.synth(n, p, 41)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    K = ops.bGaussKernel(ctx.from_numpy(Xs), float(p))
+    monkeypatch.setenv("BIGKRLS_EIGK", "dense")
+    d = ops.bEigen(K, neig, 0.001)
+    monkeypatch.delenv("BIGKRLS_EIGK")
+    a = ops.bEigen(K, neig, 0.001)
+    assert a.lastkeeper == d.lastkeeper
+    assert np.max(np.abs(np.asarray(a.values) - np.asarray(d.values))) <= 1e-10 * d.values[0]
+    Qa = a.vectors.to_numpy()
+    k = a.lastkeeper
+    assert np.max(np.abs(Qa.T @ Qa - np.eye(k))) < 1e-11
+    KQ = ops.gemm(False, False, K, a.vectors).to_numpy()
+    assert np.max(np.linalg.norm(KQ - Qa * np.asarray(a.values)[:k], axis=0)) <= 1e-9 * a.values[0]
+    # ... and as a fit: the same coefficients as with the dense decomposition
+    fa = bk.bigKRLS(y, X, Neig=neig, ctx=ctx, noisy=False, derivative=False)
+    monkeypatch.setenv("BIGKRLS_EIGK", "dense")
+    fd = bk.bigKRLS(y, X, Neig=neig, ctx=ctx, noisy=False, derivative=False)
+    assert fa["lastkeeper"] == fd["lastkeeper"]
+    assert abs(fa["lambda"] - fd["lambda"]) <= 1e-8 * abs(fd["lambda"])
+    assert np.max(np.abs(fa["coeffs"] - fd["coeffs"])) <= 1e-7 * np.max(np.abs(fd["coeffs"]))
+    assert ctx.counters()["redone"] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nbytes", [1, 8, 65535, 65536 * 2 + 8, (16 << 20) * 2, (16 << 20) * 5 + 24])
 def test_c_abi_host_copies_round_trip(lib, ctx, nbytes):
     """bigkrls_h2d / bigkrls_d2h with caller (pageable) memory: from one byte to 80 MB + 24, byte for byte."""
