@@ -31,6 +31,9 @@ WORLD_CASES = {
     # lambda / c / eigenvalues come back bitwise identical on both ranks, the deviating rank counts the event
     "dense_world2_ulp_replica": ["900", "4", "2", "--eigtrunc", "0.001", "--ulp-rank", "1"],
     "krylov_world2_ulp_replica": ["17000", "10", "2", "--krylov", "60", "--ulp-rank", "1"],
+    # a numerically low-rank kernel (P = 2) through the sharded block Lanczos: ill-conditioned blocks re-orthogonalised with
+    # all-reduced coefficients, the check as soon as the Krylov space is invariant -- the same decisions on both ranks
+    "krylov_world2_low_rank": ["17000", "2", "2", "--krylov", "512"],
     # The product's own communicator path (unique id -> bigkrls_comm_create -> the dlopen'd function table, collectives
     # asynchronous on the context's stream) over tests/mock_rccl, with the library's DEFAULT kernels ("--default-knobs":
     # the persistent panel factorisation / bulge chasing beside the collectives; a watchdog that fires because the rank
