@@ -2554,7 +2554,9 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   }
 #endif
   if (!converged && dim < k) {
-    set_error("eigen (Krylov): breakdown with a subspace smaller than the number of requested pairs");
+    set_error("eigen (Krylov): breakdown with a subspace smaller than the number of requested pairs (a kernel of lower "
+              "numerical rank than Neig: the dense path decomposes it -- taken automatically on one GPU; "
+              "bigkrls_fit_dist: eigen_mode \"dense\")");
     return BIGKRLS_ENOCONV;
   }
   if (!converged) {

@@ -15,6 +15,11 @@ sizes = [2, 3, 17, 63, 64, 65, 66, 127, 129, 255, 256, 257, 258, 300, 321, 449, 
 # rows, i.e. n >= 13 121), pairs below (>= 10 752)
 if len(sys.argv) > 1 and sys.argv[1] == "large":
     sizes = [7999, 8000, 8001, 8033, 8191, 10751, 11009, 11073, 13055, 13121, 13185, 13377, 13441, 14001]
+# round 6: the panel chain on one stream below 6 144 trailing rows (every n crosses it; the first panels of n = 6 2xx start
+# just above), eight panels per merged back-transform block at every size, the dense path at the sizes where the block
+# Lanczos takes over for Neig << N
+if len(sys.argv) > 1 and sys.argv[1] == "r6":
+    sizes = [6143, 6207, 6208, 6209, 6273, 6337, 12863, 12929, 16383, 16384, 16385, 20011]
 bad = 0
 for n in sizes:
     p = 4
