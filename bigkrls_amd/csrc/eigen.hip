@@ -2289,6 +2289,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
   double wnorm_sq = 0.0;           // |W|_F^2 of the block the last step produced (before its QR)
   double wmax_seen = 0.0;          // the largest direction any new block had (square root of the largest Gram pivot)
   bool early_check_done = false;   // the check ahead of the schedule on a (numerically) invariant Krylov space, see below
+  double dropped = 0.0;            // |W|_F of the blocks replaced by random ones: what every residual estimate misses
   int full_steps = 0;              // steps of the last full check (0: none yet)
   bool next_is_estimate = false;   // the next check decomposes the compressed projected problem (see below)
   void* pY = nullptr;
@@ -2367,6 +2368,41 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
     // direction a millionth of the largest one any block had. Going on would normalise noise into unit vectors for
     // step after step until a pivot turns negative (P = 2: ten such steps before the first scheduled check); the
     // check comes now instead, as soon as the subspace has k columns, and decides with the true residuals.
+    // ... and while it has fewer than k columns (Neig above the numerical rank of K), the block that is nothing but
+    // rounding is REPLACED by a fresh random block orthogonalised against all blocks so far (what ARPACK does on an
+    // invariant subspace): normalising the rounding instead works for a few steps, then the noise -- amplified by K
+    // from step to step -- turns ill-conditioned and a pivot negative, short of k columns. The replaced W is what the
+    // block recurrence loses: only a block below 1e-10 of the largest direction seen -- below the tolerance times
+    // lambda_1, since no direction of a W exceeds lambda_1 -- is replaced, and its norm enters every later residual.
+    // beta of this step is zero (the new block is not coupled to the old ones).
+    {
+      const double wfro = std::sqrt(std::max(wnorm_sq, 0.0));
+      if (wmax_seen > 0.0 && wfro <= 1e-10 * wmax_seen && (int64_t)(steps + 1) * b < k && steps + 1 < maxsteps) {
+        BK_TRY(fill_random(ctx, W, n * b, 20240229u + 7919u * (uint32_t)(steps + 1)));
+        for (int pass = 0; pass < 2; ++pass) {
+          BK_TRY(gram(B, dim, W, b, C));
+          if (nr > 0) BK_TRY(gemm(ctx, 0, 0, nr, b, dim, -1.0, B + ro, n, C, dim, 1.0, W + ro, n));
+        }
+        std::vector<double> Rr;
+        bool bdr = false;
+        BK_TRY(kry_cholqr(ctx, &W, &W2, n, b, dG, Rr, &bdr, nullptr, comm, ro, nr));
+        {
+          double okv = bdr ? 0.0 : 1.0;
+          BK_TRY(kry_agree_min(kop, &okv, 1));
+          bdr = !(okv > 0.5);
+        }
+        if (!bdr) {
+          breakdown = false;
+          dropped = std::max(dropped, wfro);
+          std::fill(Rtmp.begin(), Rtmp.end(), 0.0);
+          BK_HIP(hipMemsetAsync(dBall + (int64_t)steps * b * b, 0, (size_t)b * b * sizeof(double), st));
+          piv[1] = 0.0;       // (nothing of this step counts as a direction of a Krylov block)
+          if (getenv("BIGKRLS_VERBOSE"))
+            fprintf(stderr, "[bigkrls] block Lanczos step %d: invariant subspace of %lld columns (|W| = %.1e): continued with a random block\n",
+                    steps, (long long)((steps + 1) * b), wfro);
+        }
+      }
+    }
     {
       const double wmax = std::sqrt(std::max(piv[1], 0.0));
       if (!breakdown && !early_check_done && wmax <= 1e-6 * wmax_seen && (int64_t)(steps + 1) * b >= k) {
@@ -2409,6 +2445,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
           if (std::sqrt(r2) <= tol * std::fabs(th[0])) ++r.n_conv;
           if (keep_thresh >= 0.0 && th[i] >= keep_thresh * th[0]) r.worst_kept = std::max(r.worst_kept, std::sqrt(r2));
         }
+        r.worst = std::max(r.worst, dropped);      // (blocks replaced by random ones, see the step loop)
         return r;
       };
       // the m x m projected matrix (estimate == false), or the compressed one of the estimate (below), is decomposed by the

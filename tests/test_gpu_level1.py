@@ -438,12 +438,13 @@ def test_eigen_block_lanczos_matches_dense_and_arpack(lib, monkeypatch, n, p, ne
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p,neig", [(2, 512), (3, 384), (1, 256)])
+@pytest.mark.parametrize("p,neig", [(2, 512), (2, 1536), (3, 384), (1, 256)])
 def test_eigen_block_lanczos_on_numerically_low_rank_kernels(lib, monkeypatch, p, neig):
     """Kernels of one to three columns fall below rounding long before Neig eigenvalues (numerical rank ~20 / ~150 /
     ~600 at N = 17 000): the block Krylov space becomes invariant to working precision after a few steps. The library's
     default choice (N >= 16384, Neig <= N/8: block Lanczos) must then stop and decide on true residuals instead of
     normalising rounding noise into basis vectors (P = 2, 3), re-orthogonalise the ill-conditioned blocks on the way,
+    fill up with random blocks when the invariant subspace has fewer than Neig columns (P = 2, Neig = 1536),
     and hand a breakdown before the subspace has Neig columns to the dense path (P = 1) -- the same pairs as the dense
     path in every case (the reference's eigs_sym branch has no such restriction, src/eigen.cpp:18-22)."""
     import bigkrls_amd as bk
