@@ -2393,7 +2393,7 @@ static int eigen_krylov(bigkrls_ctx* ctx, const KTimes& kop, int64_t n, int64_t 
         }
         if (!bdr) {
           breakdown = false;
-          dropped = std::max(dropped, wfro);
+          dropped += wfro;                 // (a bound for what all the replaced blocks together took from the recurrence)
           std::fill(Rtmp.begin(), Rtmp.end(), 0.0);
           BK_HIP(hipMemsetAsync(dBall + (int64_t)steps * b * b, 0, (size_t)b * b * sizeof(double), st));
           piv[1] = 0.0;       // (nothing of this step counts as a direction of a Krylov block)
